@@ -1,0 +1,148 @@
+"""
+ctypes binding of libfcdiff_hip.so (C ABI: include/fcdiff_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (or `make -C fcdiff_amd/csrc`).  There is no
+CPU fallback anywhere in this package: a missing library, a missing GPU or a non-zero return code raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcdiff_hip.so")
+
+FCD_OK = 0
+FCD_ERR_ARG = -1
+FCD_ERR_SHAPE = -2
+FCD_ERR_UNSUPPORTED = -3
+FCD_ERR_INDEX = -4
+EDGE_REFERENCE = 0
+EDGE_SYMMETRIC = 1
+EDGE_MODES = {"reference": EDGE_REFERENCE, "symmetric": EDGE_SYMMETRIC}
+ABI_VERSION = 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_int = C.c_int
+_dbl = C.c_double
+
+# name -> (restype, argtypes); one entry per declaration of include/fcdiff_hip.h
+SIGNATURES = {
+    "fcd_abi_version": (_int, []),
+    "fcd_strerror": (C.c_char_p, [_int]),
+    "fcd_last_message": (C.c_char_p, [_p]),
+    "fcd_ctx_create": (_int, [C.POINTER(_p)]),
+    "fcd_ctx_destroy": (_int, [_p]),
+    "fcd_ctx_reserve": (_int, [_p, _i64, _i64, _i64]),
+    "fcd_N_to_C": (_i64, [_i64]),
+    "fcd_C_to_N": (_i64, [_i64]),
+    "fcd_nm_to_c": (_i64, [_i64, _i64]),
+    "fcd_c_to_nm": (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "fcd_hyper_set": (_int, [_p, _p, C.POINTER(_dbl), C.POINTER(_dbl), _p]),
+    "fcd_lik_tables": (_int, [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_dbl), _p, _p, _p, _p, _p]),
+    "fcd_vb_update_qF": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "fcd_vb_update_qR": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "fcd_vb_energy": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "fcd_vb_theta_step": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "fcd_gibbs_state_size": (_int, [_i64, _i64, _i64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "fcd_gibbs_init": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _u64, _dbl, _p]),
+    "fcd_gibbs_f_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _p]),
+    "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
+    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
+    "fcd_gibbs_stats": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "fcd_gibbs_mstep": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "fcd_gibbs_accumulate": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "fcd_gibbs_logjoint": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "fcd_gibbs_conditionals": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+    "fcd_gibbs_export_state": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "fcd_gibbs_import_state": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "fcd_philox_uniforms": (_int, [_p, _p, _i64, _u64, _p, _p]),
+}
+
+_lib = None
+
+
+class FcdiffHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol of the header (raises when it is not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "fcdiff_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fcdiff_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.fcd_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError("fcdiff_amd: libfcdiff_hip.so has ABI %d, this package expects %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    """Map a return code to the exception the reference's NumPy path would have raised."""
+    if rc == FCD_OK:
+        return
+    lib = load()
+    msg = lib.fcd_last_message(ctx).decode() if ctx else ""
+    base = lib.fcd_strerror(rc).decode()
+    text = msg if msg else base
+    if rc == FCD_ERR_SHAPE or rc == FCD_ERR_ARG:
+        raise ValueError(text)
+    if rc == FCD_ERR_INDEX:
+        raise IndexError(text)
+    if rc == FCD_ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    raise FcdiffHipError("HIP error %d: %s %s" % (rc, base, msg))
+
+
+class Context(object):
+    """Owns one fcd_ctx on the current torch CUDA (HIP) device."""
+
+    def __init__(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("fcdiff_amd needs an MI355X: torch.cuda.is_available() is False "
+                               "(the fit path has no CPU fallback)")
+        self.lib = load()
+        self.handle = _p()
+        check(self.lib.fcd_ctx_create(C.byref(self.handle)))
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def close(self):
+        if self.handle:
+            self.lib.fcd_ctx_destroy(self.handle)
+            self.handle = _p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        check(getattr(self.lib, name)(self.handle, *args), self.handle)
+
+
+def stream_ptr():
+    import torch
+    return _p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return _p(0) if t is None else _p(t.data_ptr())
+
+
+def dbl_array(values):
+    import numpy as np
+    a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    return (a.ctypes.data_as(C.POINTER(_dbl)), a)

@@ -1,0 +1,99 @@
+// Context, error strings and the host-side index maps of libfcdiff_hip.so.
+#include <new>
+
+#include "fcd_common.h"
+
+int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return FCD_OK;
+    // grow: the old block may still be in use by kernels already queued, so drain first
+    FCD_HIP_TRY(hipDeviceSynchronize());
+    if (ctx->ws) FCD_HIP_TRY(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    FCD_HIP_TRY(hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return FCD_OK;
+}
+
+extern "C" {
+
+int fcd_abi_version(void) { return FCD_ABI_VERSION; }
+
+const char *fcd_strerror(int code) {
+    switch (code) {
+        case FCD_OK: return "ok";
+        case FCD_ERR_ARG: return "invalid argument (null pointer or non-positive size)";
+        case FCD_ERR_SHAPE: return "invalid shape (number of connections must be a triangular number, Nreg >= 2)";
+        case FCD_ERR_UNSUPPORTED: return "shape outside what the gfx950 kernels are built for";
+        case FCD_ERR_INDEX: return "reference edge id out of range";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown fcdiff_hip error";
+}
+
+const char *fcd_last_message(const fcd_ctx *ctx) { return ctx ? ctx->msg : ""; }
+
+int fcd_ctx_create(fcd_ctx **out) {
+    if (!out) return FCD_ERR_ARG;
+    *out = nullptr;
+    int dev = 0;
+    FCD_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FCD_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    fcd_ctx *ctx = new (std::nothrow) fcd_ctx();
+    if (!ctx) return (int)hipErrorOutOfMemory;
+    ctx->device = dev;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    ctx->msg[0] = 0;
+    int rc = fcd_ws_reserve(ctx, 1u << 20);
+    if (rc) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return FCD_OK;
+}
+
+int fcd_ctx_destroy(fcd_ctx *ctx) {
+    if (!ctx) return FCD_OK;
+    hipError_t e = hipSuccess;
+    if (ctx->ws) e = hipFree(ctx->ws);
+    delete ctx;
+    return (int)e;
+}
+
+int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
+    if (!ctx || Nreg < 2 || U < 1 || G < 1) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_reserve: bad argument");
+    const int64_t GW = (G + 63) / 64;
+    size_t need = (size_t)64 * GW * 64 * sizeof(double);        // log-joint partials
+    const size_t en = (size_t)ctx->num_cu * 8 * 8 * sizeof(double);  // energy partials
+    if (en > need) need = en;
+    return fcd_ws_reserve(ctx, need);
+}
+
+int64_t fcd_N_to_C(int64_t Nreg) { return fcd_tri(Nreg); }
+
+int64_t fcd_C_to_N(int64_t C) {
+    if (C < 1) return FCD_ERR_SHAPE;
+    int64_t n = (int64_t)((sqrt(8.0 * (double)C + 1.0) - 1.0) * 0.5) + 1;
+    while (fcd_tri(n) > C) --n;
+    while (fcd_tri(n + 1) <= C) ++n;
+    return fcd_tri(n) == C ? n : (int64_t)FCD_ERR_SHAPE;
+}
+
+int64_t fcd_nm_to_c(int64_t n, int64_t m) { return fcd_tri(n) + m; }
+
+int fcd_c_to_nm(int64_t c, int64_t *n, int64_t *m) {
+    if (c < 0 || !n || !m) return FCD_ERR_ARG;
+    int nn, mm;
+    fcd_edge_to_pair(c, nn, mm);
+    *n = nn;
+    *m = mm;
+    return FCD_OK;
+}
+
+}  // extern "C"

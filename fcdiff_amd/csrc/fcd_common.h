@@ -1,0 +1,135 @@
+// Shared host/device helpers of libfcdiff_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fcdiff_hip.h"
+
+struct fcd_ctx {
+    int device;
+    int num_cu;
+    void *ws;          // reduction / partial-sum workspace
+    size_t ws_bytes;
+    char msg[256];
+};
+
+#define FCD_HIP_TRY(expr)                       \
+    do {                                        \
+        hipError_t e__ = (expr);                \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+#define FCD_LAUNCH_CHECK()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+static inline int fcd_fail(fcd_ctx *ctx, int code, const char *fmt, long long a = 0, long long b = 0) {
+    if (ctx) snprintf(ctx->msg, sizeof(ctx->msg), fmt, a, b);
+    return code;
+}
+
+int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
+
+// hyper block offsets
+#define FCD_H_LNGAMMA 0
+#define FCD_H_LNPI0 3
+#define FCD_H_LNPI1 4
+
+// RNG kinds (4th counter word)
+#define FCD_KIND_INIT_F 0u
+#define FCD_KIND_INIT_R 1u
+#define FCD_KIND_F 2u
+#define FCD_KIND_R 3u
+
+// ---------------------------------------------------------------------------------------------
+// edge <-> region-pair maps, fcdiff/util.py:40-84.  c = n(n-1)/2 + m, n > m.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline int64_t fcd_tri(int64_t n) { return n * (n - 1) / 2; }
+
+// Inverse with an integer correction step (the reference's float sqrt formula, util.py:82, is only
+// trusted near perfect squares up to the sizes it was written for).
+__host__ __device__ static inline void fcd_edge_to_pair(int64_t c, int &n, int &m) {
+    int64_t nn = (int64_t)((sqrt(8.0 * (double)c + 1.0) - 1.0) * 0.5) + 1;
+    while (fcd_tri(nn) > c) --nn;
+    while (fcd_tri(nn + 1) <= c) ++nn;
+    n = (int)nn;
+    m = (int)(c - fcd_tri(nn));
+}
+
+// Edge id the region update uses for the ORDERED pair (n, m), m != n.
+__host__ __device__ static inline int64_t fcd_pair_to_edge(int n, int m, int mode) {
+    if (mode == FCD_EDGE_REFERENCE || n > m) return fcd_tri(n) + m;  // fit.py:186 / util.py:60
+    return fcd_tri(m) + n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Random123 constants).  counter = (idx, chain, sweep, kind), key = seed.
+// ---------------------------------------------------------------------------------------------
+struct fcd_u4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ static inline fcd_u4 fcd_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return fcd_u4{c0, c1, c2, c3};
+}
+
+// 53 high bits of (hi:lo) as a double in [0, 1).
+__host__ __device__ static inline double fcd_u53(uint32_t hi, uint32_t lo) {
+    uint64_t w = ((uint64_t)hi << 32) | lo;
+    return (double)(w >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ static inline double fcd_site_uniform(uint64_t seed, uint32_t idx, uint32_t chain,
+                                                          uint32_t sweep, uint32_t kind, int half) {
+    fcd_u4 x = fcd_philox(idx, chain, sweep, kind, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return half ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// draws: identical formulas in oracle/fcdiff_oracle.py (draw_f, draw_r) and oracle/fcdiff_oracle.c
+// ---------------------------------------------------------------------------------------------
+__device__ static inline int fcd_draw_f(double a0, double a1, double a2, double x) {
+    double mx = fmax(a0, fmax(a1, a2));
+    double e0 = exp(a0 - mx), e1 = exp(a1 - mx), e2 = exp(a2 - mx);
+    double t = x * ((e0 + e1) + e2);
+    return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
+}
+
+__device__ static inline int fcd_draw_r(double s0, double s1, double x) {
+    double p1 = 1.0 / (1.0 + exp(s0 - s1));
+    return x < p1 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------------
+__device__ static inline double fcd_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// per-lane select driven by a wave-uniform 64-bit mask held in an SGPR pair:
+// lane i gets (mask bit i) ? b : a.  One v_cndmask_b32, no per-lane shift.
+__device__ static inline uint32_t fcd_sel_mask(uint32_t a, uint32_t b, uint64_t mask) {
+    uint32_t out;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
+    return out;
+}

@@ -1,0 +1,655 @@
+// Many-chain collapsed Gibbs sampler over (f, r) for the IAR model, built on the reference's per-edge
+// tables.  The two conditionals are fcdiff/fit.py:170-173 (f) and :187-194 (r) at one-hot q.
+//
+// Mapping: lane = chain.  A wave owns one "chain word" (64 chains); everything that does not depend
+// on the chain (edge id, patient, region pair, table tile) is wave-uniform and lives in SGPRs / LDS:
+//   * r is stored as bit planes r_bits[w][n][u] (one uint64 = r_nu of the 64 chains of word w), so
+//     the mixture index l(r_nu, r_mu) of all 64 chains comes from two scalar masks and becomes a
+//     per-lane LDS byte offset with two v_cndmask;
+//   * f is stored as f_state[w][c][64] bytes: a wave reads/writes 64 contiguous bytes per edge.
+//
+// Algorithmic bytes per sweep of G chains: 2*72*C*U (lM once per pass) + 24*C +
+// G*(2*C + 3*Nreg*U) of state.  Arithmetic: 3 (f) + 4 (r) fp64 adds per (edge, patient, chain).
+#include "fcd_common.h"
+
+namespace {
+
+__device__ inline uint64_t active_mask(int w, int64_t G) {
+    const int64_t rem = G - (int64_t)w * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------
+// init
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gibbs_init_f(uint8_t *__restrict__ f_state, int64_t C, int GW, uint32_t chain0,
+                                                    uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (w, pair of edges)
+    const int64_t n_pairs = (C + 1) / 2;
+    if (item >= n_pairs * GW) return;
+    const int w = (int)(item / n_pairs);
+    const int64_t pr = item % n_pairs;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const fcd_u4 x = fcd_philox((uint32_t)pr, chain, 0u, FCD_KIND_INIT_F, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int f0 = min((int)(fcd_u53(x.x, x.y) * 3.0), 2);
+    const int f1 = min((int)(fcd_u53(x.z, x.w) * 3.0), 2);
+    const int64_t c = pr * 2;
+    f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)f0;
+    if (c + 1 < C) f_state[((int64_t)w * C + c + 1) * 64 + lane] = (uint8_t)f1;
+}
+
+__global__ __launch_bounds__(256) void gibbs_init_r(uint64_t *__restrict__ r_bits, int Nreg, int U, int GW,
+                                                    uint32_t chain0, uint64_t seed, double pi) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_np = (Nreg + 1) / 2;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (w, region pair, u)
+    if (item >= n_np * U * GW) return;
+    const int w = (int)(item / (n_np * U));
+    const int64_t rest = item % (n_np * U);
+    const int np = (int)(rest / U), u = (int)(rest % U);
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const fcd_u4 x = fcd_philox((uint32_t)(np * U + u), chain, 0u, FCD_KIND_INIT_R, (uint32_t)seed,
+                                (uint32_t)(seed >> 32));
+    const uint64_t b0 = __ballot(fcd_u53(x.x, x.y) < pi);
+    const uint64_t b1 = __ballot(fcd_u53(x.z, x.w) < pi);
+    if (lane == 0) {
+        const int n = np * 2;
+        r_bits[((int64_t)w * Nreg + n) * U + u] = b0;
+        if (n + 1 < Nreg) r_bits[((int64_t)w * Nreg + n + 1) * U + u] = b1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f step.  grid.x = edge tiles of Ec edges, grid.y = groups of (blockDim/64) chain words.
+// The tile lM[c0 : c0+Ec, :, :, :] (contiguous, Ec*U*72 bytes) is staged in LDS once and read by every
+// wave of the block: with 16 waves (1024 chains) per block the table is read from HBM/L2 once per pass.
+// COND = true writes the three unnormalised log-weights instead of drawing (parity hook).
+// ---------------------------------------------------------------------------------------------
+constexpr int F_UNROLL = 8;
+template <bool COND>
+__global__ __launch_bounds__(1024) void gibbs_f_kernel(const double *__restrict__ S_B, const double *__restrict__ lM,
+                                                       const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
+                                                       const uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
+                                                       int GW, int64_t G, int Ec, uint32_t chain0, uint64_t seed,
+                                                       uint32_t sweep, double *__restrict__ cond_f) {
+    extern __shared__ double tile[];
+    const int64_t c0 = (int64_t)blockIdx.x * Ec;
+    const int ne = (int)((C - c0 < Ec) ? (C - c0) : Ec);
+    {
+        const int64_t n_dbl = (int64_t)ne * U * 9;
+        const double *src = lM + c0 * U * 9;
+        for (int64_t i = threadIdx.x; i < n_dbl; i += blockDim.x) tile[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (w >= GW) return;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const double lng0 = hyper[FCD_H_LNGAMMA + 0], lng1 = hyper[FCD_H_LNGAMMA + 1], lng2 = hyper[FCD_H_LNGAMMA + 2];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t *__restrict__ rw = r_bits + (int64_t)w * Nreg * U;
+    fcd_u4 rnd = {0, 0, 0, 0};
+    int64_t rnd_idx = -1;
+
+    for (int e = 0; e < ne; ++e) {
+        const int64_t c = c0 + e;
+        int n, m;
+        fcd_edge_to_pair(c, n, m);
+        const uint64_t *__restrict__ rn = rw + (int64_t)n * U;
+        const uint64_t *__restrict__ rm = rw + (int64_t)m * U;
+        const char *tb = reinterpret_cast<const char *>(tile + (int64_t)e * U * 9);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        // l = 1 (both anomalous) -> +8 B, l = 2 (discordant) -> +16 B, l = 0 -> +0 inside lM[c,u,k,:].
+        // Chunks of F_UNROLL patients with a fixed trip count: the masks of a chunk arrive in one wide
+        // scalar load per region and the LDS reads of a chunk are all in flight together.
+        int u = 0;
+        for (; u + F_UNROLL <= U; u += F_UNROLL) {
+#pragma unroll
+            for (int j = 0; j < F_UNROLL; ++j) {
+                const uint64_t mn = rn[u + j], mm = rm[u + j];
+                const uint32_t off = fcd_sel_mask(fcd_sel_mask(0u, 16u, mn ^ mm), 8u, mn & mm);
+                const double *p = reinterpret_cast<const double *>(tb + (u + j) * 72 + off);
+                a0 += p[0];
+                a1 += p[3];
+                a2 += p[6];
+            }
+        }
+        for (; u < U; ++u) {
+            const uint64_t mn = rn[u], mm = rm[u];
+            const uint32_t off = fcd_sel_mask(fcd_sel_mask(0u, 16u, mn ^ mm), 8u, mn & mm);
+            const double *p = reinterpret_cast<const double *>(tb + u * 72 + off);
+            a0 += p[0];
+            a1 += p[3];
+            a2 += p[6];
+        }
+        a0 = lng0 + (S_B[c * 3 + 0] + a0);   // fit.py:165, 171-173
+        a1 = lng1 + (S_B[c * 3 + 1] + a1);
+        a2 = lng2 + (S_B[c * 3 + 2] + a2);
+        if (COND) {
+            if ((int64_t)w * 64 + lane < G) {
+                double *o = cond_f + (((int64_t)w * 64 + lane) * C + c) * 3;
+                o[0] = a0; o[1] = a1; o[2] = a2;
+            }
+        } else {
+            if ((c >> 1) != rnd_idx) {
+                rnd_idx = c >> 1;
+                rnd = fcd_philox((uint32_t)rnd_idx, chain, sweep, FCD_KIND_F, k0, k1);
+            }
+            const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(a0, a1, a2, x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// r step, version 1.  grid = (U, GW): one block per (patient, chain word); regions strictly in order
+// (systematic scan), the four waves split the sum over the other region m.  The 64 chains' r_mu is a
+// uint64 kept in LDS (mask[m]) and refreshed by ballot after each region.
+// ---------------------------------------------------------------------------------------------
+constexpr int R_WAVES = 4;
+__global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
+                                                               const uint8_t *__restrict__ f_state,
+                                                               uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
+                                                               uint32_t chain0, uint64_t seed, uint32_t sweep, int mode) {
+    extern __shared__ uint64_t sh_r[];
+    uint64_t *mask = sh_r;                                         // [Nreg]
+    double *part = reinterpret_cast<double *>(sh_r + Nreg);        // [R_WAVES][2][64]
+    const int u = blockIdx.x, w = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t *__restrict__ rcol = r_bits + (int64_t)w * Nreg * U + u;
+    for (int n = tid; n < Nreg; n += 64 * R_WAVES) mask[n] = rcol[(int64_t)n * U];
+    __syncthreads();
+    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C * 64 + lane;
+    const double *__restrict__ lMu = lM + (int64_t)u * 9;
+    const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    fcd_u4 rnd = {0, 0, 0, 0};
+
+    for (int n = 0; n < Nreg; ++n) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
+        for (int m = wave; m < Nreg; m += R_WAVES) {
+            const bool valid = (m != n);
+            const int64_t c = valid ? fcd_pair_to_edge(n, m, mode) : 0;
+            const int k = fw[c * 64];
+            const uint32_t bit = (uint32_t)((mask[m] >> lane) & 1ull);
+            const double *p = lMu + (c * U) * 9 + k * 3;
+            // r_m = 0: (lM[k,0], lM[k,2]);  r_m = 1: (lM[k,2], lM[k,1])      fit.py:188-194
+            const double v0 = p[bit * 2];
+            const double v1 = p[2 - bit];
+            s0 += valid ? v0 : 0.0;
+            s1 += valid ? v1 : 0.0;
+        }
+        part[(wave * 2 + 0) * 64 + lane] = s0;
+        part[(wave * 2 + 1) * 64 + lane] = s1;
+        __syncthreads();
+        if (wave == 0) {
+            double t0 = part[0 * 64 + lane], t1 = part[1 * 64 + lane];
+#pragma unroll
+            for (int j = 1; j < R_WAVES; ++j) {
+                t0 += part[(j * 2 + 0) * 64 + lane];
+                t1 += part[(j * 2 + 1) * 64 + lane];
+            }
+            if ((n & 1) == 0)
+                rnd = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
+            const double x = (n & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            const uint64_t ball = __ballot(fcd_draw_r(lnpi0 + t0, lnpi1 + t1, x));
+            if (lane == 0) mask[n] = ball;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Nreg; n += 64 * R_WAVES) rcol[(int64_t)n * U] = mask[n];
+}
+
+// conditional log-weights of every r site given the CURRENT state (nothing updated): parity hook.
+__global__ __launch_bounds__(64) void gibbs_cond_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
+                                                          const uint8_t *__restrict__ f_state,
+                                                          const uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
+                                                          int64_t G, int mode, double *__restrict__ cond_r) {
+    const int u = blockIdx.x, w = blockIdx.y, n = blockIdx.z, lane = threadIdx.x;
+    const uint8_t *fw = f_state + (int64_t)w * C * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
+    for (int m = 0; m < Nreg; ++m) {
+        if (m == n) continue;
+        const int64_t c = fcd_pair_to_edge(n, m, mode);
+        const int k = fw[c * 64];
+        const uint32_t bit = (uint32_t)((r_bits[((int64_t)w * Nreg + m) * U + u] >> lane) & 1ull);
+        const double *p = lM + (c * U + u) * 9 + k * 3;
+        s0 += p[bit * 2];
+        s1 += p[2 - bit];
+    }
+    const int64_t g = (int64_t)w * 64 + lane;
+    if (g < G) {
+        double *o = cond_r + ((g * Nreg + n) * U + u) * 2;
+        o[0] = hyper[FCD_H_LNPI0] + s0;
+        o[1] = hyper[FCD_H_LNPI1] + s1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooled statistics, marginal counters, M-step
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gibbs_stats_kernel(const uint8_t *__restrict__ f_state,
+                                                          const uint64_t *__restrict__ r_bits, int64_t C, int64_t NU, int GW,
+                                                          int64_t G, unsigned long long *__restrict__ counts) {
+    __shared__ unsigned long long red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long cr = 0, c0 = 0, c1 = 0, c2 = 0;
+    // f: one wave per (w, c) row of 64 bytes
+    const int64_t rows = (int64_t)GW * C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int w = (int)(row / C);
+        const uint64_t act = active_mask(w, G);
+        const int f = f_state[row * 64 + lane];
+        const uint64_t b0 = __ballot(f == 0) & act, b1 = __ballot(f == 1) & act, b2 = __ballot(f == 2) & act;
+        if (lane == 0) {
+            c0 += __popcll(b0);
+            c1 += __popcll(b1);
+            c2 += __popcll(b2);
+        }
+    }
+    // r: one thread per word
+    const int64_t words = (int64_t)GW * NU;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i / NU);
+        cr += __popcll(r_bits[i] & active_mask(w, G));
+    }
+    // integer sums: any order gives the same result
+    for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+    if (lane == 0) {
+        red[wave][0] = cr; red[wave][1] = c0; red[wave][2] = c1; red[wave][3] = c2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (s) atomicAdd(&counts[threadIdx.x], s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 4) counts[4] = (unsigned long long)G;
+}
+
+__global__ void gibbs_mstep_kernel(const long long *__restrict__ counts, double sites_per_chain_r, double C,
+                                   double *__restrict__ hyper) {
+    const double Gtot = (double)counts[4];
+    const double n_r = Gtot * sites_per_chain_r;
+    double pi = (double)counts[0] / n_r;                  // fit.py:213 over chains
+    const double lo = 0.5 / n_r;
+    pi = fmin(fmax(pi, lo), 1.0 - lo);
+    hyper[FCD_H_LNPI0] = log(1.0 - pi);
+    hyper[FCD_H_LNPI1] = log(pi);
+    const double n_f = Gtot * C;
+    for (int k = 0; k < 3; ++k) {
+        double g = (double)counts[1 + k] / n_f;           // fit.py:220 over chains
+        g = fmax(g, 0.5 / n_f);
+        hyper[FCD_H_LNGAMMA + k] = log(g);
+    }
+}
+
+__global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restrict__ f_state,
+                                                          const uint64_t *__restrict__ r_bits, int64_t C, int64_t NU, int GW,
+                                                          int64_t G, uint32_t *__restrict__ cnt_f, uint32_t *__restrict__ cnt_r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < C; c += (int64_t)gridDim.x * 4) {
+        uint32_t n0 = 0, n1 = 0, n2 = 0;
+        for (int w = 0; w < GW; ++w) {
+            const uint64_t act = active_mask(w, G);
+            const int f = f_state[((int64_t)w * C + c) * 64 + lane];
+            n0 += __popcll(__ballot(f == 0) & act);
+            n1 += __popcll(__ballot(f == 1) & act);
+            n2 += __popcll(__ballot(f == 2) & act);
+        }
+        if (lane == 0) {
+            cnt_f[c * 3 + 0] += n0;
+            cnt_f[c * 3 + 1] += n1;
+            cnt_f[c * 3 + 2] += n2;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NU; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t s = 0;
+        for (int w = 0; w < GW; ++w) s += __popcll(r_bits[(int64_t)w * NU + i] & active_mask(w, G));
+        cnt_r[i] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-joint per chain: grid = (GW, LJ_SLICES); slice s sums edges c = s, s+LJ_SLICES, ... and (slice 0) the
+// prior of r; partial[s][g] in the workspace, folded in slice order.
+// ---------------------------------------------------------------------------------------------
+constexpr int LJ_SLICES = 64;
+__global__ __launch_bounds__(64) void gibbs_logjoint_kernel(const double *__restrict__ S_B, const double *__restrict__ lM,
+                                                            const double *__restrict__ hyper,
+                                                            const uint8_t *__restrict__ f_state,
+                                                            const uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
+                                                            int GW, double *__restrict__ partial) {
+    const int w = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    const uint64_t *rw = r_bits + (int64_t)w * Nreg * U;
+    double acc = 0.0;
+    for (int64_t c = s; c < C; c += LJ_SLICES) {
+        int n, m;
+        fcd_edge_to_pair(c, n, m);
+        const int k = f_state[((int64_t)w * C + c) * 64 + lane];
+        double e = hyper[FCD_H_LNGAMMA + k] + S_B[c * 3 + k];
+        for (int u = 0; u < U; ++u) {
+            const uint32_t a = (uint32_t)((rw[(int64_t)n * U + u] >> lane) & 1ull);
+            const uint32_t b2 = (uint32_t)((rw[(int64_t)m * U + u] >> lane) & 1ull);
+            const int l = (a & b2) ? 1 : ((a ^ b2) ? 2 : 0);
+            e += lM[(c * U + u) * 9 + k * 3 + l];
+        }
+        acc += e;
+    }
+    if (s == 0) {
+        int ones = 0;
+        for (int64_t i = 0; i < (int64_t)Nreg * U; ++i) ones += (int)((rw[i] >> lane) & 1ull);
+        acc += (double)ones * hyper[FCD_H_LNPI1] + (double)((int64_t)Nreg * U - ones) * hyper[FCD_H_LNPI0];
+    }
+    partial[((int64_t)s * GW + w) * 64 + lane] = acc;
+}
+
+__global__ void gibbs_logjoint_fold(const double *__restrict__ partial, int64_t GWx64, int64_t G, double *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double acc = 0.0;
+    for (int s = 0; s < LJ_SLICES; ++s) acc += partial[(int64_t)s * GWx64 + g];
+    out[g] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed <-> plain state
+// ---------------------------------------------------------------------------------------------
+__global__ void export_f_kernel(const uint8_t *__restrict__ f_state, int64_t C, int64_t G, uint8_t *__restrict__ f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over G*C, c fastest
+    if (i >= G * C) return;
+    const int64_t g = i / C, c = i % C;
+    f[i] = f_state[((g >> 6) * C + c) * 64 + (g & 63)];
+}
+__global__ void export_r_kernel(const uint64_t *__restrict__ r_bits, int64_t NU, int64_t G, uint8_t *__restrict__ r) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over G*NU
+    if (i >= G * NU) return;
+    const int64_t g = i / NU, j = i % NU;
+    r[i] = (uint8_t)((r_bits[(g >> 6) * NU + j] >> (g & 63)) & 1ull);
+}
+__global__ void import_f_kernel(const uint8_t *__restrict__ f, int64_t C, int64_t G, int GW, uint8_t *__restrict__ f_state) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over GW*C*64
+    if (i >= (int64_t)GW * C * 64) return;
+    const int64_t lane = i & 63, c = (i >> 6) % C, w = (i >> 6) / C;
+    const int64_t g = w * 64 + lane;
+    f_state[i] = g < G ? f[g * C + c] : 0;
+}
+__global__ __launch_bounds__(256) void import_r_kernel(const uint8_t *__restrict__ r, int64_t NU, int64_t G, int GW,
+                                                       uint64_t *__restrict__ r_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // over GW*NU
+    if (word >= (int64_t)GW * NU) return;
+    const int64_t w = word / NU, j = word % NU;
+    const int64_t g = w * 64 + lane;
+    const uint64_t ball = __ballot(g < G ? (r[g * NU + j] != 0) : false);
+    if (lane == 0) r_bits[word] = ball;
+}
+
+__global__ void philox_uniforms_kernel(const uint32_t *__restrict__ ctr4, int64_t n, uint64_t seed, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fcd_u4 x = fcd_philox(ctr4[i * 4 + 0], ctr4[i * 4 + 1], ctr4[i * 4 + 2], ctr4[i * 4 + 3], (uint32_t)seed,
+                                (uint32_t)(seed >> 32));
+    out[i * 2 + 0] = fcd_u53(x.x, x.y);
+    out[i * 2 + 1] = fcd_u53(x.z, x.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+    int64_t C;
+    int GW;
+};
+
+int geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, Geo &g) {
+    if (!ctx) return FCD_ERR_ARG;
+    if (Nreg < 2 || U < 1 || G < 1)
+        return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2, U >= 1, G >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
+    if (Nreg > 46340 || U > (1 << 20) || G > (1ll << 31) || chain0 < 0 || chain0 + G > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "shape out of range (Nreg=%lld, G=%lld)", Nreg, G);
+    g.C = fcd_tri(Nreg);
+    g.GW = (int)((G + 63) / 64);
+    if (g.GW > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "G=%lld exceeds 65535 chain words per launch", G);
+    if ((Nreg + 1) / 2 * U > (1ll << 32) || (g.C + 1) / 2 > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "site index exceeds the 32-bit counter word");
+    return FCD_OK;
+}
+
+// edges per LDS tile of the f step and waves per block
+void f_step_geometry(int64_t U, int GW, int &Ec, int &wpb, size_t &shmem) {
+    wpb = GW < 16 ? GW : 16;
+    const size_t per_edge = (size_t)U * 72;
+    int64_t e = (int64_t)(32 * 1024 / per_edge);
+    if (e < 1) e = 1;
+    if (e > 8) e = 8;
+    if (e > 1) e &= ~1ll;  // even: both halves of a Philox block are used inside one tile
+    Ec = (int)e;
+    shmem = per_edge * Ec;
+}
+
+template <bool COND>
+int launch_f(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper, uint8_t *f_state,
+             const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, const Geo &g, int64_t chain0, uint64_t seed,
+             int64_t sweep, double *cond_f, hipStream_t s) {
+    int Ec, wpb;
+    size_t shmem;
+    f_step_geometry(U, g.GW, Ec, wpb, shmem);
+    if (shmem > 160 * 1024)
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "f step: one edge's table row (U=%lld patients) exceeds the 160 KiB LDS", U);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_kernel<COND>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((unsigned)((g.C + Ec - 1) / Ec), (unsigned)((g.GW + wpb - 1) / wpb));
+    hipLaunchKernelGGL(gibbs_f_kernel<COND>, grid, dim3(64 * wpb), shmem, s, S_B, lM, hyper, f_state, r_bits, (int)Nreg,
+                       (int)U, g.C, g.GW, G, Ec, (uint32_t)chain0, seed, (uint32_t)sweep, cond_f);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+}  // namespace
+
+extern "C" int fcd_gibbs_state_size(int64_t Nreg, int64_t U, int64_t G, size_t *f_bytes, size_t *r_bytes) {
+    if (Nreg < 2 || U < 1 || G < 1 || !f_bytes || !r_bytes) return FCD_ERR_ARG;
+    const int64_t GW = (G + 63) / 64;
+    *f_bytes = (size_t)(GW * fcd_tri(Nreg) * 64);
+    *r_bytes = (size_t)(GW * Nreg * U * 8);
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                              int64_t chain0, uint64_t seed, double pi, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_init: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t items_f = (g.C + 1) / 2 * g.GW;
+    hipLaunchKernelGGL(gibbs_init_f, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, g.C, g.GW,
+                       (uint32_t)chain0, seed);
+    FCD_LAUNCH_CHECK();
+    const int64_t items_r = (Nreg + 1) / 2 * U * g.GW;
+    hipLaunchKernelGGL(gibbs_init_r, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, g.GW,
+                       (uint32_t)chain0, seed, pi);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                                uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                                int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
+    if (rc) return rc;
+    if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_f_step: null pointer");
+    return launch_f<false>(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, g, chain0, seed, sweep, nullptr,
+                           (hipStream_t)stream);
+}
+
+extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *hyper, const uint8_t *f_state,
+                                uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
+                                int64_t sweep, int edge_mode, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
+    if (rc) return rc;
+    if (!lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: null pointer");
+    if (edge_mode != FCD_EDGE_REFERENCE && edge_mode != FCD_EDGE_SYMMETRIC)
+        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: edge_mode %lld", edge_mode);
+    if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
+        return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
+    const size_t shmem = (size_t)Nreg * 8 + (size_t)R_WAVES * 2 * 64 * 8;
+    if (shmem > 64 * 1024) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld exceeds the LDS mask array", Nreg);
+    hipLaunchKernelGGL(gibbs_r_kernel, dim3((unsigned)U, (unsigned)g.GW), dim3(64 * R_WAVES), shmem, (hipStream_t)stream,
+                       lM, hyper, f_state, r_bits, (int)Nreg, (int)U, g.C, (uint32_t)chain0, seed, (uint32_t)sweep,
+                       edge_mode);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                               int64_t G, int64_t *counts, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits || !counts) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_stats: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    FCD_HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), s));
+    int64_t blocks = ((int64_t)g.GW * g.C + 3) / 4;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gibbs_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f_state, r_bits, g.C, Nreg * U, g.GW, G,
+                       reinterpret_cast<unsigned long long *>(counts));
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                                uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                                uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
+                                fcd_stream stream) {
+    if (n_sweeps < 0 || sweep0 < 0 || sweep0 + n_sweeps > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_sweeps: sweep range [%lld, +%lld) outside the 32-bit counter word", sweep0, n_sweeps);
+    for (int64_t i = 0; i < n_sweeps; ++i) {
+        int rc = fcd_gibbs_f_step(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
+        if (rc) return rc;
+        rc = fcd_gibbs_r_step(ctx, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
+        if (rc) return rc;
+    }
+    if (counts && n_sweeps > 0) return fcd_gibbs_stats(ctx, f_state, r_bits, Nreg, U, G, counts, stream);
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_mstep(fcd_ctx *ctx, const int64_t *counts, int64_t Nreg, int64_t U, double *hyper,
+                               fcd_stream stream) {
+    if (!ctx || !counts || !hyper) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_mstep: null pointer");
+    if (Nreg < 2 || U < 1) return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2 and U >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
+    hipLaunchKernelGGL(gibbs_mstep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long *>(counts), (double)(Nreg * U), (double)fcd_tri(Nreg), hyper);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
+                                    int64_t U, int64_t G, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits || !cnt_f || !cnt_r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_accumulate: null pointer");
+    int64_t blocks = (g.C + 3) / 4;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gibbs_accum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f_state, r_bits, g.C,
+                       Nreg * U, g.GW, G, cnt_f, cnt_r);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                                  const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                                  double *out, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!S_B || !lM || !hyper || !f_state || !r_bits || !out) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_logjoint: null pointer");
+    const size_t need = (size_t)LJ_SLICES * g.GW * 64 * sizeof(double);
+    rc = fcd_ws_reserve(ctx, need);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gibbs_logjoint_kernel, dim3((unsigned)g.GW, LJ_SLICES), dim3(64), 0, s, S_B, lM, hyper, f_state,
+                       r_bits, (int)Nreg, (int)U, g.C, g.GW, (double *)ctx->ws);
+    FCD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gibbs_logjoint_fold, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, (const double *)ctx->ws,
+                       (int64_t)g.GW * 64, G, out);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_conditionals(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                                      const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                                      int64_t G, int edge_mode, double *cond_f, double *cond_r, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_conditionals: null pointer");
+    if (edge_mode != FCD_EDGE_REFERENCE && edge_mode != FCD_EDGE_SYMMETRIC)
+        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_conditionals: edge_mode %lld", edge_mode);
+    if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2 && cond_r)
+        return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
+    hipStream_t s = (hipStream_t)stream;
+    if (cond_f) {
+        rc = launch_f<true>(ctx, S_B, lM, hyper, const_cast<uint8_t *>(f_state), r_bits, Nreg, U, G, g, 0, 0, 0, cond_f, s);
+        if (rc) return rc;
+    }
+    if (cond_r) {
+        if (U > 65535 || Nreg > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_gibbs_conditionals: grid too large");
+        hipLaunchKernelGGL(gibbs_cond_r_kernel, dim3((unsigned)U, (unsigned)g.GW, (unsigned)Nreg), dim3(64), 0, s, lM, hyper,
+                           f_state, r_bits, (int)Nreg, (int)U, g.C, G, edge_mode, cond_r);
+        FCD_LAUNCH_CHECK();
+    }
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_export_state(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
+                                      int64_t U, int64_t G, uint8_t *f, uint8_t *r, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits || !f || !r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_export_state: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(export_f_kernel, dim3((unsigned)((G * g.C + 255) / 256)), dim3(256), 0, s, f_state, g.C, G, f);
+    FCD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(export_r_kernel, dim3((unsigned)((G * Nreg * U + 255) / 256)), dim3(256), 0, s, r_bits, Nreg * U, G, r);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_import_state(fcd_ctx *ctx, const uint8_t *f, const uint8_t *r, int64_t Nreg, int64_t U,
+                                      int64_t G, uint8_t *f_state, uint64_t *r_bits, fcd_stream stream) {
+    Geo g;
+    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits || !f || !r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_import_state: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nf = (int64_t)g.GW * g.C * 64;
+    hipLaunchKernelGGL(import_f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, f, g.C, G, g.GW, f_state);
+    FCD_LAUNCH_CHECK();
+    const int64_t words = (int64_t)g.GW * Nreg * U;
+    hipLaunchKernelGGL(import_r_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, s, r, Nreg * U, G, g.GW, r_bits);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_philox_uniforms(fcd_ctx *ctx, const uint32_t *ctr4, int64_t n, uint64_t seed, double *out,
+                                   fcd_stream stream) {
+    if (!ctx || !ctr4 || !out || n < 0) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_philox_uniforms: bad argument");
+    if (n == 0) return FCD_OK;
+    hipLaunchKernelGGL(philox_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctr4, n,
+                       seed, out);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}

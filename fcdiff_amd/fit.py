@@ -1,0 +1,516 @@
+"""
+Fits models to observed correlations -- the MI355X build of fcdiff/fit.py.
+
+`UnsharedRegionFit` keeps the reference's surface (fcdiff/fit.py:12-54): attributes `model, b, bt,
+max_iters=10, rel_tol=1e-5, energy`, private state `_lq_R (N,U,2), _lq_F (C,1,3), _lp_B_g_F (C,H,3),
+_p_Bt_g_Ft (C,U,3), _lM (C,U,3,3)` readable/assignable as NumPy arrays, `run()` and the private methods
+its tests call (`_init_lps, _update_lps, _update_lq_F, _update_lq_R, _update_pi, _update_gamma,
+_update_theta, _eval_energy, _is_converged`).  Every one of them runs a hand-written HIP kernel
+through the C ABI (include/fcdiff_hip.h) on tensors that stay on the GPU between calls.  There is no
+NumPy fallback: without libfcdiff_hip.so or a GPU these methods raise.
+
+New knobs (all optional; defaults reproduce the reference):
+    method       'vb' (reference algorithm) | 'gibbs' (many-chain collapsed Gibbs + MCEM for pi, gamma)
+    edge_index   'reference' (fit.py:185-186 calls nm_to_c for every ordered pair: quirk Q1) |
+                 'symmetric' (doc/methods.rst:646-653).  Default: 'reference' for vb, 'symmetric' for gibbs.
+    n_chains, n_sweeps, burn_in, mstep_every, seed, chain0     sampler controls
+
+Differences from the reference that are deliberate and documented:
+  Q4  `model.pi` may be the scalar the model defines or the 2-vector [1-pi, pi] the reference's updates
+      index; both are accepted everywhere.
+  Q5  tables are float64 (the reference's np.full(shape, 1) buffers turn int64 on modern NumPy).
+  Q7  run() is the documented loop (doc/methods.rst:564-600); `energy` is appended to.  The reference's
+      run() raises IndexError on its first energy assignment (fit.py:73-74).  The (eta, epsilon)
+      optimiser step (fit.py:222-241) cannot run in the reference (calls undefined names) and is not
+      part of this round (`update_theta_sub` stays False).
+"""
+import numpy as np
+
+from . import _lib
+from . import util
+from .gibbs import GibbsEngine, run_chains, allreduce_counts
+
+
+class UnsharedRegionFit(object):
+    """
+    Fits an unshared region model to correlations (fcdiff/fit.py:12-30).
+
+    Attributes
+    ----------
+    model : fcdiff_amd.UnsharedRegionModel      initial model; updated in place by run()
+    b : ndarray (C, H), bt : ndarray (C, U)     correlations of healthy subjects / patients
+    max_iters : int, rel_tol : float            iteration cap / relative tolerance of _is_converged
+    energy : list of float                      variational free energy per iteration (vb) or minus the
+                                                chain-mean log-joint per recorded sweep (gibbs)
+    """
+
+    def __init__(self):
+        self.model = None
+        self.b = None
+        self.bt = None
+        self.max_iters = 10
+        self.rel_tol = 1e-5
+        self.energy = []
+
+        self.method = "vb"
+        self.edge_index = None
+        self.update_theta_sub = False
+        self.n_chains = 1024
+        self.n_sweeps = 100
+        self.burn_in = 20
+        self.mstep_every = 1
+        self.energy_every = 0
+        self.seed = 0
+        self.chain0 = 0
+        self.sampler = None       # the GibbsEngine of the last gibbs run
+
+        self._ctx = None
+        self._d = {}              # device tensors: lq_R, lq_F, S_B, lM, lpB, pBt, hyper, b, bt
+        self._hyper_key = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = _lib.Context()
+        return self._ctx
+
+    def _torch(self):
+        import torch
+        return torch
+
+    def _dev(self):
+        return self._context().device
+
+    def _up(self, a):
+        t = self._torch()
+        return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self._dev())
+
+    def _edge_mode(self):
+        name = self.edge_index
+        if name is None:
+            name = "reference" if self.method == "vb" else "symmetric"
+        if name not in _lib.EDGE_MODES:
+            raise ValueError("edge_index must be 'reference' or 'symmetric'")
+        return name
+
+    def _shape(self):
+        lM = self._d.get("lM")
+        if lM is None:
+            raise ValueError("tables have not been initialized (_init_lps / _update_lps)")
+        C, U = int(lM.shape[0]), int(lM.shape[1])
+        return int(round(float(util.C_to_N(C)))), C, U
+
+    def _hyper(self):
+        """Device hyper block {ln gamma, ln(1-pi), ln pi} refreshed whenever the model's values changed."""
+        t = self._torch()
+        if "hyper" not in self._d:
+            self._d["hyper"] = t.zeros(8, dtype=t.float64, device=self._dev())
+        gamma = np.asarray(self.model.gamma, dtype=np.float64).reshape(3)
+        pi2 = self._pi2()
+        key = (tuple(gamma.tolist()), tuple(pi2.tolist()))
+        if key != self._hyper_key:
+            (g, _g) = _lib.dbl_array(gamma)
+            (p, _p) = _lib.dbl_array(pi2)
+            self._context().call("fcd_hyper_set", _lib.dptr(self._d["hyper"]), g, p, _lib.stream_ptr())
+            self._hyper_key = key
+        return self._d["hyper"]
+
+    def _pi2(self):
+        pi = np.asarray(self.model.pi, dtype=np.float64)
+        if pi.ndim == 0:
+            return np.array([1.0 - float(pi), float(pi)])
+        return pi.reshape(2)
+
+    # ------------------------------------------------------------------ NumPy views of the device state
+    def _get(self, key, shape=None):
+        v = self._d.get(key)
+        if v is None:
+            return None
+        a = v.cpu().numpy()
+        return a.reshape(shape) if shape is not None else a
+
+    @property
+    def _lq_R(self):
+        return self._get("lq_R")
+
+    @_lq_R.setter
+    def _lq_R(self, a):
+        self._d["lq_R"] = None if a is None else self._up(a)
+
+    @property
+    def _lq_F(self):
+        return self._get("lq_F")
+
+    @_lq_F.setter
+    def _lq_F(self, a):
+        self._d["lq_F"] = None if a is None else self._up(a)
+
+    @property
+    def _lM(self):
+        return self._get("lM")
+
+    @_lM.setter
+    def _lM(self, a):
+        self._d["lM"] = None if a is None else self._up(a)
+
+    @property
+    def _lp_B_g_F(self):
+        """(C,H,3).  The fit path only ever uses its H-sum; the full table is produced on demand."""
+        if self._d.get("lpB") is None and self.b is not None and self.model is not None and "S_B" in self._d:
+            self._tables(full=True)
+        return self._get("lpB")
+
+    @_lp_B_g_F.setter
+    def _lp_B_g_F(self, a):
+        if a is None:
+            self._d["lpB"] = None
+            return
+        self._d["lpB"] = self._up(a)
+        self._d["S_B"] = self._d["lpB"].sum(dim=1).contiguous()      # fit.py:171 sums over H
+
+    @property
+    def _p_Bt_g_Ft(self):
+        if self._d.get("pBt") is None and self.bt is not None and self.model is not None and "lM" in self._d:
+            self._tables(full=True)
+        return self._get("pBt")
+
+    @_p_Bt_g_Ft.setter
+    def _p_Bt_g_Ft(self, a):
+        self._d["pBt"] = None if a is None else self._up(a)
+
+    # ------------------------------------------------------------------ reference methods
+    def run(self):
+        """Runs the fitting procedure (fcdiff/fit.py:56-82; doc/methods.rst:564-600)."""
+        (C, H) = self.b.shape
+        U = self.bt.shape[1]
+        N = util.C_to_N(C)
+        if (N % 1) != 0:
+            msg = "Number of connections (%u) must be a triangular number." % C
+            raise ValueError(msg)
+        if self.model is None:
+            msg = "Model has not been initialized."
+            raise ValueError(msg)
+        N = int(N)
+        self._init_lps(N, H, U)
+        self._update_lps()
+        if self.method == "vb":
+            self._run_vb()
+        elif self.method == "gibbs":
+            self._run_gibbs(N, U)
+        else:
+            raise ValueError("method must be 'vb' or 'gibbs'")
+
+    def _run_vb(self):
+        self.energy = [self._eval_energy()]
+        for i in range(1, self.max_iters + 1):
+            self._update_lq_F()
+            self._update_lq_R()
+            self._update_theta()
+            self._update_lps()
+            self.energy.append(self._eval_energy())
+            if self._is_converged(i):
+                break
+
+    def _init_lps(self, N, H, U):
+        """Uniform log-probabilities and float64 tables (fit.py:84-102)."""
+        t = self._torch()
+        dev = self._dev()
+        C = util.N_to_C(N)
+        self._d["lq_R"] = t.full((N, U, 2), -np.log(2), dtype=t.float64, device=dev)
+        self._d["lq_F"] = t.full((C, 1, 3), -np.log(3), dtype=t.float64, device=dev)
+        self._d["S_B"] = t.full((C, 3), float(H), dtype=t.float64, device=dev)
+        self._d["lM"] = t.ones((C, U, 3, 3), dtype=t.float64, device=dev)
+        self._d["lpB"] = None
+        self._d["pBt"] = None
+        self._HU = (H, U)
+
+    def _update_lps(self):
+        """Likelihood tables from the current parameters (fit.py:104-122): kernel K_lik."""
+        self._tables(full=False)
+
+    def _tables(self, full):
+        t = self._torch()
+        dev = self._dev()
+        b = np.ascontiguousarray(self.b, dtype=np.float64)
+        bt = np.ascontiguousarray(self.bt, dtype=np.float64)
+        (C, H) = b.shape
+        U = bt.shape[1]
+        if self._d.get("b_src") is not self.b or self._d.get("bt_src") is not self.bt:
+            self._d["b"], self._d["bt"] = self._up(b), self._up(bt)      # uploaded once per dataset
+            self._d["b_src"], self._d["bt_src"] = self.b, self.bt
+        if self._d.get("S_B") is None or tuple(self._d["S_B"].shape) != (C, 3):
+            self._d["S_B"] = t.empty((C, 3), dtype=t.float64, device=dev)
+        if self._d.get("lM") is None or tuple(self._d["lM"].shape) != (C, U, 3, 3):
+            self._d["lM"] = t.empty((C, U, 3, 3), dtype=t.float64, device=dev)
+        lpB = pBt = None
+        if full:
+            lpB = t.empty((C, H, 3), dtype=t.float64, device=dev)
+            pBt = t.empty((C, U, 3), dtype=t.float64, device=dev)
+        (th, _th) = _lib.dbl_array(self.model.theta())
+        self._context().call("fcd_lik_tables", _lib.dptr(self._d["b"]), _lib.dptr(self._d["bt"]), C, H, U, th,
+                             _lib.dptr(self._d["S_B"]), _lib.dptr(self._d["lM"]), _lib.dptr(lpB), _lib.dptr(pBt),
+                             _lib.stream_ptr())
+        self._d["lpB"], self._d["pBt"] = lpB, pBt
+
+    def _is_converged(self, s):
+        """fit.py:124-140 (quirk Q6 kept: a negative energy makes any decrease 'converged')."""
+        e = self.energy[s - 1]
+        e_star = self.energy[s]
+        return ((e - e_star) / e) < self.rel_tol
+
+    def _eval_energy(self):
+        """Variational free energy (fit.py:142-155): kernel K_energy."""
+        return float(self._energy_terms_signed().sum())
+
+    def _energy_terms(self):
+        t = self._torch()
+        (N, C, U) = self._shape()
+        out = t.empty(6, dtype=t.float64, device=self._dev())
+        self._context().call("fcd_vb_energy", _lib.dptr(self._d["lq_F"]), _lib.dptr(self._d["lq_R"]),
+                             _lib.dptr(self._d["S_B"]), _lib.dptr(self._d["lM"]), _lib.dptr(self._hyper()), N, U,
+                             _lib.dptr(out), _lib.stream_ptr())
+        return out.cpu().numpy()
+
+    def _energy_terms_signed(self):
+        return self._energy_terms() * np.array([-1.0, -1.0, -1.0, -1.0, 1.0, 1.0])
+
+    def _update_lq_F(self):
+        """Probability of the typical network template (fit.py:157-174): kernel K_qF."""
+        t = self._torch()
+        (N, C, U) = self._shape()
+        out = t.empty((C, 1, 3), dtype=t.float64, device=self._dev())
+        self._context().call("fcd_vb_update_qF", _lib.dptr(self._d["lq_R"]), _lib.dptr(self._d["S_B"]),
+                             _lib.dptr(self._d["lM"]), _lib.dptr(self._hyper()), N, U, _lib.dptr(out),
+                             _lib.stream_ptr())
+        self._d["lq_F"] = out
+
+    def _update_lq_R(self):
+        """Probability of the anomalous regions (fit.py:176-198): kernel K_qR (Gauss-Seidel over regions)."""
+        (N, C, U) = self._shape()
+        lq_R = self._d["lq_R"].clone()
+        self._context().call("fcd_vb_update_qR", _lib.dptr(self._d["lq_F"]), _lib.dptr(self._d["lM"]),
+                             _lib.dptr(self._hyper()), N, U, _lib.EDGE_MODES[self._edge_mode()], _lib.dptr(lq_R),
+                             _lib.stream_ptr())
+        self._d["lq_R"] = lq_R
+
+    def _update_theta(self):
+        """fit.py:200-206."""
+        self._update_pi()
+        self._update_gamma()
+        if self.update_theta_sub:
+            self._update_theta_sub()
+
+    def _theta_step(self):
+        t = self._torch()
+        lq_R, lq_F = self._d["lq_R"], self._d["lq_F"]
+        (N, U) = (int(lq_R.shape[0]), int(lq_R.shape[1]))
+        if util.N_to_C(N) != int(lq_F.shape[0]):
+            raise ValueError("_lq_F and _lq_R disagree on the number of regions")
+        out = t.empty(4, dtype=t.float64, device=self._dev())
+        self._context().call("fcd_vb_theta_step", _lib.dptr(lq_F), _lib.dptr(lq_R), N, U, _lib.dptr(out),
+                             _lib.dptr(None), _lib.stream_ptr())
+        return out.cpu().numpy()
+
+    def _update_pi(self):
+        """pi* = mean q_R[:, :, 1] (fit.py:208-213); a scalar, as in the reference."""
+        t = self._torch()
+        lq_R = self._d["lq_R"]
+        if self._d.get("lq_F") is None:      # the reference's test sets only _lq_R
+            N = int(lq_R.shape[0])
+            self._d["lq_F"] = t.full((util.N_to_C(N), 1, 3), -np.log(3), dtype=t.float64, device=self._dev())
+        self.model.pi = float(self._theta_step()[0])
+
+    def _update_gamma(self):
+        """gamma* = mean_c q_F (fit.py:215-220)."""
+        t = self._torch()
+        lq_F = self._d["lq_F"]
+        if self._d.get("lq_R") is None:      # the reference's test sets only _lq_F
+            N = int(round(float(util.C_to_N(int(lq_F.shape[0])))))
+            self._d["lq_R"] = t.full((N, 1, 2), -np.log(2), dtype=t.float64, device=self._dev())
+        self.model.gamma = self._theta_step()[1:4].copy()
+
+    def _update_theta_sub(self):
+        raise NotImplementedError(
+            "the (eta, epsilon) optimiser step cannot run in the reference (fit.py:239 calls the undefined "
+            "self.opt_fun) and is scheduled after the hot path (SURVEY.md section 8f item 1)")
+
+    # ------------------------------------------------------------------ gibbs
+    def _run_gibbs(self, N, U):
+        """
+        Many-chain collapsed Gibbs over (f, r) with an MCEM step for (pi, gamma) from statistics pooled
+        over all chains of all ranks.  On return `_lq_F` / `_lq_R` hold the logs of the chain-and-sweep
+        averaged marginals, `model.pi` / `model.gamma` the last M-step, `energy` minus the mean
+        log-joint at the recorded sweeps.
+        """
+        t = self._torch()
+        eng = GibbsEngine(self._d["S_B"], self._d["lM"], N, U, self.n_chains, chain0=self.chain0, seed=self.seed,
+                          edge_index=self._edge_mode(), ctx=self._context())
+        pi2 = self._pi2()
+        eng.set_hyper(np.asarray(self.model.gamma, dtype=np.float64), pi2)
+        eng.init(float(pi2[1]))
+        self.energy = []
+
+        def record(i, e):
+            if self.energy_every and (i + 1) % self.energy_every == 0:
+                self.energy.append(-float(e.logjoint().mean()))
+        run_chains(eng, self.n_sweeps, sweep0=0, mstep_every=self.mstep_every, burn_in=self.burn_in,
+                   update_theta=True, on_sweep=record)
+        self.sampler = eng
+        # marginals pooled over this rank's chains and, when distributed, over all ranks
+        cnt = t.cat([eng.cnt_f.reshape(-1).to(t.int64), eng.cnt_r.reshape(-1).to(t.int64),
+                     t.tensor([eng.n_accumulated * eng.G], dtype=t.int64, device=eng.cnt_f.device)])
+        cnt = allreduce_counts(cnt).cpu().numpy().astype(np.float64)
+        C = util.N_to_C(N)
+        total = max(cnt[-1], 1.0)
+        with np.errstate(divide="ignore"):
+            self._lq_F = np.log(cnt[:3 * C].reshape(C, 1, 3) / total)
+            p1 = cnt[3 * C:3 * C + N * U].reshape(N, U) / total
+            self._lq_R = np.log(np.stack([1.0 - p1, p1], axis=2))
+        (gamma, pi) = eng.hyper_values()
+        self.model.gamma = gamma
+        self.model.pi = pi
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Module-level helpers of the reference (fcdiff/fit.py:382-733).  They are small closed forms on whole arrays
+# that the reference's tests call directly; the fit path itself evaluates them inside the kernels above.
+# Kept as NumPy one-liners with the reference's names, argument order and return shapes.
+# ---------------------------------------------------------------------------------------------------------
+def _eval_q_R_w(q_R, n, m):
+    """(U,3) weights of a region pair: both typical, both anomalous, discordant (fit.py:382-406)."""
+    w = np.zeros((q_R.shape[1], 3))
+    w[:, 0] = q_R[n, :, 0] * q_R[m, :, 0]
+    w[:, 1] = q_R[n, :, 1] * q_R[m, :, 1]
+    w[:, 2] = q_R[n, :, 0] * q_R[m, :, 1]
+    w[:, 2] += q_R[n, :, 1] * q_R[m, :, 0]
+    return w
+
+
+def _eval_M_eps(eta, epsilon, l):
+    """Probability of keeping the template type under mixture case l (fit.py:433-444)."""
+    if l == 0:
+        return 1 - epsilon
+    if l == 1:
+        return epsilon
+    eps = eta * epsilon
+    eps += (1 - eta) * (1 - epsilon)
+    return eps
+
+
+def _eval_M(N, eta, epsilon, k, l):
+    """M_kl from the Normal densities N (C,U,3) (fit.py:409-430)."""
+    eps = _eval_M_eps(eta, epsilon, l)
+    others = [j for j in range(3) if j != k]
+    return eps * N[:, :, k] + (1 - eps) * 0.5 * (N[:, :, others[0]] + N[:, :, others[1]])
+
+
+def _eval_E_lp_F(q_F, gamma):
+    return np.sum(q_F * np.log(gamma))
+
+
+def _eval_E_lp_B_g_F(q_F, lp_B_g_F):
+    return np.sum(q_F * lp_B_g_F)
+
+
+def _eval_E_lp_R(q_R, pi):
+    return np.sum(q_R * np.log(pi))
+
+
+def _eval_E_lM(q_F, q_R, lM):
+    """E[log p(bt | f, r)] (fit.py:489-511), vectorised over edges."""
+    C = q_F.shape[0]
+    N = q_R.shape[0]
+    (n, m) = np.tril_indices(N, -1)       # lower-triangular row-major == util.c_to_nm order
+    assert n.shape[0] == C
+    w = np.stack([q_R[n, :, 0] * q_R[m, :, 0], q_R[n, :, 1] * q_R[m, :, 1],
+                  q_R[n, :, 0] * q_R[m, :, 1] + q_R[n, :, 1] * q_R[m, :, 0]], axis=2)      # (C,U,3)
+    return np.sum(q_F[:, 0, :] * np.einsum("cul,cukl->ck", w, lM))
+
+
+def _eval_E_lq_F(q_F, lq_F):
+    return np.sum(q_F * lq_F)
+
+
+def _eval_E_lq_R(q_R, lq_R):
+    return np.sum(q_R * lq_R)
+
+
+def _eval_dlN_dm(b, mu, sigma):
+    return (b - mu) / (sigma * sigma)
+
+
+def _eval_dlN_ds(b, mu, sigma):
+    diff = b - mu
+    sigma2 = sigma * sigma
+    return ((diff * diff) - sigma2) / (2 * sigma2)
+
+
+def _eval_dN_dm(N, b, mu, sigma):
+    return N * _eval_dlN_dm(b, mu, sigma)
+
+
+def _eval_dN_ds(N, b, mu, sigma):
+    return N * _eval_dlN_ds(b, mu, sigma)
+
+
+def _eval_dlM_dm(norm, mix, mu, sigma, eta, epsilon, k, l):
+    """fit.py:572-597, quirk Q8 included (tests k != l; passes the density array where b is expected)."""
+    eps = _eval_M_eps(eta, epsilon, l)
+    if k != l:
+        eps = 0.5 * (1 - eps)
+    return eps * _eval_dlN_dm(norm, mu, sigma) / mix
+
+
+def _eval_dlM_dh(norm, mix, epsilon, k):
+    """fit.py:618-641."""
+    eps = (2 * epsilon) - 1
+    others = [j for j in range(3) if j != k]
+    s = norm[:, :, others[0]] + norm[:, :, others[1]]
+    return (eps * norm[:, :, k] - 0.5 * eps * s) / mix
+
+
+def _eval_dlM_de(norm, mix, eta, k, l):
+    """fit.py:667-697."""
+    eps = -1 if l == 0 else (1 if l == 1 else 2 * eta - 1)
+    others = [j for j in range(3) if j != k]
+    s = norm[:, :, others[0]] + norm[:, :, others[1]]
+    return (eps * norm[:, :, k] - 0.5 * eps * s) / mix
+
+
+def _pair_weights(q_R):
+    N = q_R.shape[0]
+    (n, m) = np.tril_indices(N, -1)
+    w0 = q_R[n, :, 0] * q_R[m, :, 0]
+    w1 = q_R[n, :, 1] * q_R[m, :, 1]
+    w2 = q_R[n, :, 0] * q_R[m, :, 1] + q_R[n, :, 1] * q_R[m, :, 0]
+    return w0, w1, w2
+
+
+def _eval_dE_dm(q_F, q_R, dlN_dmj, dlM_dmj, j):
+    """dE/dmu_j (fit.py:542-569), vectorised over edges."""
+    (w0, w1, w2) = _pair_weights(q_R)
+    w = np.stack([w0, w1, w2], axis=2)
+    d = -np.sum(q_F[:, 0, j] * np.sum(dlN_dmj, axis=1))
+    d -= np.sum(q_F[:, 0, :] * np.einsum("cul,cukl->ck", w, dlM_dmj))
+    return d
+
+
+def _eval_dE_dh(q_R, q_F, norm, mix, epsilon):
+    """dE/deta (fit.py:600-615)."""
+    (_w0, _w1, w2) = _pair_weights(q_R)
+    d = 0.0
+    for k in range(3):
+        d -= np.sum(q_F[:, 0, k] * np.sum(w2 * _eval_dlM_dh(norm, mix[:, :, k, 2], epsilon, k), axis=1))
+    return d
+
+
+def _eval_dE_de(q_R, q_F, norm, mix, eta):
+    """dE/depsilon (fit.py:644-664)."""
+    (w0, w1, w2) = _pair_weights(q_R)
+    d = 0.0
+    for k in range(3):
+        s = w0 * _eval_dlM_de(norm, mix[:, :, k, 0], eta, k, 0)
+        s += w1 * _eval_dlM_de(norm, mix[:, :, k, 1], eta, k, 1)
+        s += w2 * _eval_dlM_de(norm, mix[:, :, k, 2], eta, k, 2)
+        d -= np.sum(q_F[:, 0, k] * np.sum(s, axis=1))
+    return d

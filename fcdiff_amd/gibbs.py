@@ -1,0 +1,181 @@
+"""
+Many-chain collapsed Gibbs sampler for the IAR model on one MI355X, plus the multi-GPU driver.
+
+The reference ships only the variational fitter (doc/methods.rst:236-239); this sampler is the build's
+extension named by BASELINE.json.  Its conditionals are the reference's updates at one-hot q
+(fcdiff/fit.py:170-173 for f, :187-194 for r), its M-step for (pi, gamma) the sample version of
+fit.py:208-220 -- see include/fcdiff_hip.h for the kernel-level contract.
+
+Multi-GPU (one process per GPU, torch.distributed, backend "nccl" = RCCL): chains are independent given
+the tables, so rank k simply owns global chain ids [chain0, chain0 + G).  The only exchange is the
+all-reduce of the 8-word pooled-count vector before an M-step; there is no data-path collective.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import util
+
+
+def shard_chains(total_chains, world_size, rank):
+    """Contiguous split of global chain ids: returns (chain0, n_local).  Earlier ranks take the remainder."""
+    base, rem = divmod(int(total_chains), int(world_size))
+    n_local = base + (1 if rank < rem else 0)
+    chain0 = rank * base + min(rank, rem)
+    return chain0, n_local
+
+
+def allreduce_counts(counts, group=None):
+    """Sum the pooled sufficient statistics over ranks (RCCL on GPUs, gloo on CPU); no-op for one process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
+def mstep_from_counts(counts, Nreg, U):
+    """Host restatement of fcd_gibbs_mstep (used to report pi/gamma; the device keeps its own copy)."""
+    counts = [int(x) for x in counts]
+    G = counts[4]
+    n_r = float(G * Nreg * U)
+    pi = min(max(counts[0] / n_r, 0.5 / n_r), 1.0 - 0.5 / n_r)
+    n_f = float(G * util.N_to_C(Nreg))
+    gamma = np.array([max(counts[1 + k] / n_f, 0.5 / n_f) for k in range(3)])
+    return pi, gamma
+
+
+class GibbsEngine(object):
+    """
+    Device-resident state of G chains and the kernels that move it.
+
+    S_B (C,3) and lM (C,U,3,3) are float64 CUDA tensors produced by `fcd_lik_tables`; they are shared by
+    all chains.  State layout (include/fcdiff_hip.h): f_state (GW, C, 64) uint8, r_bits (GW, Nreg, U)
+    uint64 bit planes (held in an int64 tensor), GW = ceil(G / 64).
+    """
+
+    def __init__(self, S_B, lM, Nreg, U, n_chains, chain0=0, seed=0, edge_index="symmetric", ctx=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx if ctx is not None else _lib.Context()
+        self.Nreg, self.U, self.G = int(Nreg), int(U), int(n_chains)
+        self.C = util.N_to_C(self.Nreg)
+        self.GW = (self.G + 63) // 64
+        self.chain0, self.seed = int(chain0), int(seed)
+        self.edge_mode = _lib.EDGE_MODES[edge_index]
+        if tuple(lM.shape) != (self.C, self.U, 3, 3) or tuple(S_B.shape) != (self.C, 3):
+            raise ValueError("tables do not match Nreg=%d, U=%d" % (self.Nreg, self.U))
+        self.S_B, self.lM = S_B.contiguous(), lM.contiguous()
+        dev = self.S_B.device
+        self.hyper = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.f_state = torch.zeros((self.GW, self.C, 64), dtype=torch.uint8, device=dev)
+        self.r_bits = torch.zeros((self.GW, self.Nreg, self.U), dtype=torch.int64, device=dev)
+        self.counts = torch.zeros(8, dtype=torch.int64, device=dev)
+        self.cnt_f = torch.zeros((self.C, 3), dtype=torch.int32, device=dev)
+        self.cnt_r = torch.zeros((self.Nreg, self.U), dtype=torch.int32, device=dev)
+        self.n_accumulated = 0
+        self.ctx.call("fcd_ctx_reserve", self.Nreg, self.U, self.G)
+
+    # ---- hyper-parameters ----
+    def set_hyper(self, gamma, pi2):
+        (g, _g) = _lib.dbl_array(gamma)
+        (p, _p) = _lib.dbl_array(pi2)
+        self.ctx.call("fcd_hyper_set", _lib.dptr(self.hyper), g, p, _lib.stream_ptr())
+
+    def hyper_values(self):
+        h = self.hyper.cpu().numpy()
+        return np.exp(h[0:3]), float(np.exp(h[4]))
+
+    # ---- state ----
+    def init(self, pi):
+        self.ctx.call("fcd_gibbs_init", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      self.chain0, C.c_uint64(self.seed), float(pi), _lib.stream_ptr())
+
+    def export_state(self):
+        t = self.torch
+        f = t.empty((self.G, self.C), dtype=t.uint8, device=self.f_state.device)
+        r = t.empty((self.G, self.Nreg, self.U), dtype=t.uint8, device=self.f_state.device)
+        self.ctx.call("fcd_gibbs_export_state", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U,
+                      self.G, _lib.dptr(f), _lib.dptr(r), _lib.stream_ptr())
+        return f.cpu().numpy(), r.cpu().numpy()
+
+    def import_state(self, f, r):
+        t = self.torch
+        f = t.as_tensor(np.ascontiguousarray(f, dtype=np.uint8), device=self.f_state.device)
+        r = t.as_tensor(np.ascontiguousarray(r, dtype=np.uint8), device=self.f_state.device)
+        if tuple(f.shape) != (self.G, self.C) or tuple(r.shape) != (self.G, self.Nreg, self.U):
+            raise ValueError("state shapes must be (G, C) and (G, Nreg, U)")
+        self.ctx.call("fcd_gibbs_import_state", _lib.dptr(f), _lib.dptr(r), self.Nreg, self.U, self.G,
+                      _lib.dptr(self.f_state), _lib.dptr(self.r_bits), _lib.stream_ptr())
+
+    # ---- moves ----
+    def f_step(self, sweep):
+        self.ctx.call("fcd_gibbs_f_step", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.hyper),
+                      _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
+                      C.c_uint64(self.seed), int(sweep), _lib.stream_ptr())
+
+    def r_step(self, sweep):
+        self.ctx.call("fcd_gibbs_r_step", _lib.dptr(self.lM), _lib.dptr(self.hyper), _lib.dptr(self.f_state),
+                      _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0, C.c_uint64(self.seed),
+                      int(sweep), self.edge_mode, _lib.stream_ptr())
+
+    def sweeps(self, sweep0, n_sweeps, with_counts=False):
+        self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.hyper),
+                      _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
+                      C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode,
+                      _lib.dptr(self.counts if with_counts else None), _lib.stream_ptr())
+        return self.counts if with_counts else None
+
+    # ---- pooled statistics / M-step ----
+    def stats(self):
+        self.ctx.call("fcd_gibbs_stats", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      _lib.dptr(self.counts), _lib.stream_ptr())
+        return self.counts
+
+    def mstep(self, counts):
+        self.ctx.call("fcd_gibbs_mstep", _lib.dptr(counts), self.Nreg, self.U, _lib.dptr(self.hyper), _lib.stream_ptr())
+
+    def accumulate(self):
+        self.ctx.call("fcd_gibbs_accumulate", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U,
+                      self.G, _lib.dptr(self.cnt_f), _lib.dptr(self.cnt_r), _lib.stream_ptr())
+        self.n_accumulated += 1
+
+    # ---- diagnostics ----
+    def logjoint(self):
+        out = self.torch.empty(self.G, dtype=self.torch.float64, device=self.f_state.device)
+        self.ctx.call("fcd_gibbs_logjoint", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.hyper),
+                      _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, _lib.dptr(out),
+                      _lib.stream_ptr())
+        return out
+
+    def conditionals(self, want_f=True, want_r=True):
+        t = self.torch
+        dev = self.f_state.device
+        cf = t.empty((self.G, self.C, 3), dtype=t.float64, device=dev) if want_f else None
+        cr = t.empty((self.G, self.Nreg, self.U, 2), dtype=t.float64, device=dev) if want_r else None
+        self.ctx.call("fcd_gibbs_conditionals", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.hyper),
+                      _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.edge_mode,
+                      _lib.dptr(cf), _lib.dptr(cr), _lib.stream_ptr())
+        return cf, cr
+
+
+def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_theta=True, group=None,
+               on_sweep=None):
+    """
+    The sampler loop shared by UnsharedRegionFit(method='gibbs') and bench.py.
+
+    for each sweep: f step, r step; every `mstep_every` sweeps: pooled counts -> all-reduce over ranks ->
+    M-step for (pi, gamma) on the device; after `burn_in` sweeps the marginal counters accumulate.
+    `engine` is anything with sweeps/stats/mstep/accumulate (the HIP engine here; the CPU tests pass an
+    oracle-backed stand-in to exercise the multi-process logic under gloo).
+    """
+    for i in range(n_sweeps):
+        s = sweep0 + i
+        engine.sweeps(s, 1)
+        if update_theta and mstep_every > 0 and (i + 1) % mstep_every == 0:
+            counts = allreduce_counts(engine.stats(), group)
+            engine.mstep(counts)
+        if i >= burn_in:
+            engine.accumulate()
+        if on_sweep is not None:
+            on_sweep(i, engine)

@@ -1,0 +1,170 @@
+/*
+ * fcdiff_hip.h -- C ABI of libfcdiff_hip.so, the MI355X (gfx950) implementation of the fcdiff
+ * fit path.  Plain C: raw device pointers, sizes, a hipStream_t passed as void*.  No torch, no
+ * C++ types.  Every function returns 0 on success, a negative FCD_ERR_* for an argument error
+ * detected on the host, or a positive hipError_t.  Nothing throws; nothing synchronises the
+ * device unless its comment says so.  There is no global state: all of it sits behind fcd_ctx.
+ *
+ * The reference (andy-sweet/fcdiff) is pure Python/NumPy and has NO native interface; what each
+ * entry point replaces is therefore a NumPy method of fcdiff/fit.py, cited per function.  The
+ * binding a maintainer would add on the reference side is a ctypes stub.
+ *
+ * Naming follows the reference: Nreg regions ("N" there), C = Nreg(Nreg-1)/2 edges in
+ * lower-triangular row-major order c = n(n-1)/2 + m, n > m (fcdiff/util.py:40-84), H healthy
+ * subjects, U patients.  All floating point is IEEE binary64.
+ *
+ * Array layouts (all C-contiguous, device memory unless marked "host"):
+ *   b        (C, H)        correlations of healthy subjects          fcdiff/fit.py:20-21
+ *   bt       (C, U)        correlations of patients                  fcdiff/fit.py:22-23
+ *   S_B      (C, 3)        sum_h log N(b[c,h]; mu_k, sigma_k): the H-sum of _lp_B_g_F, which is all
+ *                          fit.py:171 and :472 ever consume
+ *   lM       (C, U, 3, 3)  _lM[c,u,k,l], the reference's layout       fcdiff/fit.py:48-49
+ *   lq_F     (C, 1, 3)     _lq_F                                     fcdiff/fit.py:42-43
+ *   lq_R     (Nreg, U, 2)  _lq_R                                     fcdiff/fit.py:40-41
+ *   hyper    (8,)          {ln gamma_0..2, ln(1-pi), ln pi, 0, 0, 0}: the hyper-parameters every
+ *                          conditional reads; lives on the device so an M-step never needs the host
+ *   theta    (12,) host    {pi, eta, epsilon, gamma[3], mu[3], sigma[3]}  fcdiff/model.py:31-38
+ * Chain state of the Gibbs sampler, G chains padded to GW = ceil(G/64) words of 64 chains:
+ *   f_state  (GW, C, 64)   uint8 in {0,1,2}: f_c of chain 64*w + lane at [(w*C + c)*64 + lane]
+ *   r_bits   (GW, Nreg, U) uint64: bit `lane` of [(w*Nreg + n)*U + u] is r_{n,u} of chain 64*w+lane
+ */
+#ifndef FCDIFF_HIP_H
+#define FCDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCD_ABI_VERSION 1
+
+#define FCD_OK 0
+#define FCD_ERR_ARG (-1)         /* null pointer / non-positive size */
+#define FCD_ERR_SHAPE (-2)       /* C is not a triangular number (fit.py:62-65), Nreg < 2, ... */
+#define FCD_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (message says which) */
+#define FCD_ERR_INDEX (-4)       /* reference edge ids run out of range (Nreg == 2, fit.py:186) */
+
+/* Edge id used by the region update for an ordered pair (n, m), m != n. */
+#define FCD_EDGE_REFERENCE 0 /* nm_to_c(n,m) = n(n-1)/2 + m for EVERY ordered pair, as fit.py:185-186 calls it */
+#define FCD_EDGE_SYMMETRIC 1 /* the unordered pair's edge, as doc/methods.rst:646-653 writes it */
+
+typedef struct fcd_ctx fcd_ctx;
+typedef void *fcd_stream; /* hipStream_t */
+
+int fcd_abi_version(void);
+/* Static string for any return code of this library (hipGetErrorString for positive codes). */
+const char *fcd_strerror(int code);
+/* Last host-side diagnostic of this ctx (which argument / which limit); never NULL. */
+const char *fcd_last_message(const fcd_ctx *ctx);
+
+/* Context on the CURRENT hip device: reduction workspace + device properties.  create/destroy
+ * allocate/free device memory (they synchronise); nothing else does, except that a call needing a
+ * larger workspace than any before grows it (hipMalloc) -- call fcd_ctx_reserve first to avoid that. */
+int fcd_ctx_create(fcd_ctx **out);
+int fcd_ctx_destroy(fcd_ctx *ctx);
+int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
+
+/* ---- index maps: fcdiff/util.py:7-84 (host, integer) ------------------------------------- */
+int64_t fcd_N_to_C(int64_t Nreg);
+/* Returns Nreg with C = Nreg(Nreg-1)/2, or FCD_ERR_SHAPE when C is not triangular (fit.py:62-65). */
+int64_t fcd_C_to_N(int64_t C);
+int64_t fcd_nm_to_c(int64_t n, int64_t m);
+int fcd_c_to_nm(int64_t c, int64_t *n, int64_t *m);
+
+/* ---- hyper-parameter block ---------------------------------------------------------------- */
+/* Writes hyper[0..7] from host values: gamma[3] and the 2-vector pi2 = {1-pi, pi} the reference
+ * indexes (quirk Q4: fit.py:183, :486; test_fit.py:208, 477-487).  Asynchronous on `stream`. */
+int fcd_hyper_set(fcd_ctx *ctx, double *hyper, const double *gamma3_host, const double *pi2_host,
+                  fcd_stream stream);
+
+/* ---- likelihood tables: UnsharedRegionFit._update_lps, fit.py:104-122 + _eval_M 409-444 ----
+ * Same arithmetic as the reference: linear-space Normal densities, M_kl = eps_l N_k +
+ * (1-eps_l)/2 sum_{j!=k} N_j, lM = log M (so a fully underflowed density gives -inf exactly as
+ * there).  lp_B_g_F (C,H,3) and p_Bt_g_Ft (C,U,3) are written only when non-NULL (the fit path
+ * never reads them; the Python mirror exposes them lazily). */
+int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, int64_t C, int64_t H, int64_t U,
+                   const double *theta12_host, double *S_B, double *lM, double *lp_B_g_F,
+                   double *p_Bt_g_Ft, fcd_stream stream);
+
+/* ---- variational updates ------------------------------------------------------------------ */
+/* UnsharedRegionFit._update_lq_F, fit.py:157-174 (+ _eval_q_R_w 382-406). */
+int fcd_vb_update_qF(fcd_ctx *ctx, const double *lq_R, const double *S_B, const double *lM,
+                     const double *hyper, int64_t Nreg, int64_t U, double *lq_F, fcd_stream stream);
+/* UnsharedRegionFit._update_lq_R, fit.py:176-198: Gauss-Seidel over regions, in place. */
+int fcd_vb_update_qR(fcd_ctx *ctx, const double *lq_F, const double *lM, const double *hyper,
+                     int64_t Nreg, int64_t U, int edge_mode, double *lq_R, fcd_stream stream);
+/* The six terms of _eval_energy, fit.py:142-155 / 447-539, in its order:
+ * terms6 = {E[ln p(f)], E[ln p(b|f)], E[ln p(r)], E[ln p(bt|f,r)], E[ln q_F], E[ln q_R]} (device).
+ * energy = -t0 -t1 -t2 -t3 +t4 +t5.  Deterministic (fixed reduction order). */
+int fcd_vb_energy(fcd_ctx *ctx, const double *lq_F, const double *lq_R, const double *S_B,
+                  const double *lM, const double *hyper, int64_t Nreg, int64_t U, double *terms6,
+                  fcd_stream stream);
+/* _update_pi + _update_gamma, fit.py:208-220: out4 = {mean q_R[:,:,1], mean_c q_F[c,0,:]} (device);
+ * when hyper != NULL also stores their logs there (the theta step without leaving the device). */
+int fcd_vb_theta_step(fcd_ctx *ctx, const double *lq_F, const double *lq_R, int64_t Nreg, int64_t U,
+                      double *out4, double *hyper, fcd_stream stream);
+
+/* ---- many-chain collapsed Gibbs sampler ---------------------------------------------------
+ * Build-defined (the reference ships only the variational fitter, doc/methods.rst:236-239).  Its two
+ * conditionals are the reference's updates at one-hot q:
+ *   p(f_c = k | r)      = softmax_k of fit.py:170-173 with q_R one-hot
+ *   p(r_nu = j | f, r)  = softmax_j of fit.py:187-194 with q_F, q_R one-hot
+ * Randomness: Philox4x32-10, key = seed, counter = (site, global chain id, sweep, kind), so a chain's
+ * trajectory depends only on (seed, chain id): not on G, the launch geometry or the number of GPUs. */
+int fcd_gibbs_state_size(int64_t Nreg, int64_t U, int64_t G, size_t *f_bytes, size_t *r_bytes);
+/* f ~ Uniform{0,1,2}, r ~ Bernoulli(pi) from the counter RNG (kinds 0, 1). */
+int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                   int64_t chain0, uint64_t seed, double pi, fcd_stream stream);
+/* Redraw every f_c of every chain given r (edges are conditionally independent). */
+int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                     uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                     int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream);
+/* Redraw every r_nu of every chain given f, regions in order 0..Nreg-1 (systematic scan; patients
+ * and chains in parallel). */
+int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *hyper, const uint8_t *f_state,
+                     uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
+                     int64_t sweep, int edge_mode, fcd_stream stream);
+/* n_sweeps x (f step, r step), sweeps numbered sweep0, sweep0+1, ...  When counts != NULL the pooled
+ * statistics of the LAST sweep are stored there (see fcd_gibbs_stats). */
+int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                     uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                     uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
+                     fcd_stream stream);
+/* Pooled sufficient statistics over the G chains (the all-reduce payload):
+ * counts[0..7] = {sum r, #f=0, #f=1, #f=2, G, 0, 0, 0} (int64, device, overwritten). */
+int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                    int64_t G, int64_t *counts, fcd_stream stream);
+/* M-step for (pi, gamma) from pooled counts (after the cross-GPU all-reduce): the sample version of
+ * fit.py:208-220.  Writes hyper[0..4]; pi is kept inside [1/(2n), 1-1/(2n)], n = G*Nreg*U sites. */
+int fcd_gibbs_mstep(fcd_ctx *ctx, const int64_t *counts, int64_t Nreg, int64_t U, double *hyper,
+                    fcd_stream stream);
+/* Running marginal counts over sweeps AND chains: cnt_f (C,3) += [f_c = k], cnt_r (Nreg,U) += r_nu
+ * (uint32, device); posterior marginals = counts / (sweeps * G). */
+int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
+                         int64_t U, int64_t G, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
+/* log p(f, r, b, bt; theta) of each chain = minus the first four terms of fit.py:149-152 at one-hot q.
+ * out (G,) doubles. */
+int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                       const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                       double *out, fcd_stream stream);
+/* Unnormalised conditional log-weights of EVERY site given the current state, nothing updated:
+ * cond_f (G, C, 3), cond_r (G, Nreg, U, 2).  Either may be NULL.  (Parity hook + Rao-Blackwell use.) */
+int fcd_gibbs_conditionals(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+                           const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                           int64_t G, int edge_mode, double *cond_f, double *cond_r, fcd_stream stream);
+/* Plain views of the packed state: f (G, C) uint8, r (G, Nreg, U) uint8. */
+int fcd_gibbs_export_state(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
+                           int64_t U, int64_t G, uint8_t *f, uint8_t *r, fcd_stream stream);
+int fcd_gibbs_import_state(fcd_ctx *ctx, const uint8_t *f, const uint8_t *r, int64_t Nreg, int64_t U,
+                           int64_t G, uint8_t *f_state, uint64_t *r_bits, fcd_stream stream);
+/* 53-bit uniforms of the counter RNG for a list of (idx, chain, sweep, kind) counters:
+ * out[2*i + half].  Lets a host binding check its own Philox against the device's. */
+int fcd_philox_uniforms(fcd_ctx *ctx, const uint32_t *ctr4, int64_t n, uint64_t seed, double *out,
+                        fcd_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCDIFF_HIP_H */
