@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""
+bench.py -- posterior samples/sec of the many-chain Gibbs fit path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "cfg3"): Nreg=200 regions (C=19 900 edges), 100 subjects split
+H=U=50 (SURVEY.md section 8 assumption), 1024 chains PER GPU (weak scaling: chains shard, tables replicate).
+Synthetic data from the model's own sampler at the model defaults (fcdiff/model.py:33-38), float64.
+
+One step = one full sweep of every chain on this GPU -- all C f_c draws, all Nreg*U r_nu draws -- plus the
+pooled statistics, their all-reduce over ranks (RCCL), the (pi, gamma) M-step and the marginal
+counters.  One posterior sample = one sweep of one chain; value = chains * steps / time over all ranks.
+The likelihood tables depend only on (mu, sigma, eta, epsilon), which this loop holds fixed, so they are
+built once before the timed region (and timed separately: "lik_tables").
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the r pass or the f pass,
+whichever took longer), timed with HIP events on the launch stream inside the timed region; algorithmic
+bytes per launch follow SURVEY.md section 8d (u8 state).  `cpu_baseline` is the C restatement of the same
+sampler (oracle/fcdiff_oracle.c, OpenMP over chains) on the host cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nreg", type=int, default=200)
+    ap.add_argument("--subjects", type=int, default=100)
+    ap.add_argument("--chains-per-gpu", type=int, default=1024)
+    ap.add_argument("--mstep-every", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chains", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import fcdiff_amd
+    from fcdiff_amd import _lib
+    from fcdiff_amd.gibbs import GibbsEngine, allreduce_counts
+
+    (Nreg, H, U) = (args.nreg, args.subjects // 2, args.subjects - args.subjects // 2)
+    G = args.chains_per_gpu
+    C = fcdiff_amd.N_to_C(Nreg)
+    chain0 = rank * G
+    seed = 20240601
+
+    model = fcdiff_amd.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = model.sample_fast(Nreg, H, U, seed=0)     # same data on every rank
+
+    fit = fcdiff_amd.fit.UnsharedRegionFit()
+    fit.model, fit.b, fit.bt = model, b, bt
+    fit._init_lps(Nreg, H, U)
+    fit._update_lps()                                                     # K_lik
+    torch.cuda.synchronize()
+
+    # K_lik timed on its own (it runs once per theta_sub change, outside the sweep loop)
+    lik_ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fit._update_lps()
+        e1.record()
+        torch.cuda.synchronize()
+        lik_ms.append(e0.elapsed_time(e1))
+    lik_ms = float(np.median(lik_ms))
+    lik_bytes = 8 * C * (H + U) + 24 * C + 72 * C * U
+
+    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, chain0=chain0, seed=seed, edge_index="symmetric",
+                      ctx=fit._context())
+    eng.set_hyper(model.gamma, model.pi2())
+    eng.init(float(model.pi))
+
+    ev = {"f": [], "r": []}
+
+    def step(s, timed):
+        if timed:
+            a, b_, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            a.record()
+        eng.f_step(s)
+        if timed:
+            b_.record()
+        eng.r_step(s)
+        if timed:
+            c.record()
+            ev["f"].append((a, b_))
+            ev["r"].append((b_, c))
+        if args.mstep_every and (s + 1) % args.mstep_every == 0:
+            counts = allreduce_counts(eng.stats())
+            eng.mstep(counts)
+        eng.accumulate()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s, False)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        step(s, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    f_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["f"]]))
+    r_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["r"]]))
+    # algorithmic bytes per launch, SURVEY.md section 8d (u8 state): lM once per pass + state
+    f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
+    r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
+    (dom, dom_ms, dom_bytes) = ("gibbs_r_kernel", r_ms, r_bytes) if r_ms >= f_ms else ("gibbs_f_kernel", f_ms, f_bytes)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    adds = (3 if dom == "gibbs_f_kernel" else 4) * C * U * G
+
+    out = {
+        "metric": "posterior samples/sec at R=200 ROIs, N=100 subj, 1024 chains; 1/2/4/8 GPUs",
+        "value": world * G * args.steps / elapsed,
+        "unit": "samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "cfg3: Nreg=%d (C=%d edges), H=U=%d, %d chains/GPU, collapsed Gibbs sweep + pooled "
+                               "(pi,gamma) M-step every %d sweep(s), fixed tables" % (Nreg, C, U, G, args.mstep_every),
+                   "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
+                   "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                     "note": "tables are shared by all chains and stay in the 256 MiB Infinity Cache at this size, so "
+                             "the sweep is fp64-VALU/LDS bound, not HBM bound (SURVEY 8d); fp64 adds/s below",
+                     "f64_adds_per_s": adds / (dom_ms * 1e-3)},
+        "kernels_ms": {"gibbs_f_kernel": f_ms, "gibbs_r_kernel": r_ms},
+        "lik_tables": {"bound": "hbm", "algorithmic_bytes": lik_bytes, "ms": lik_ms,
+                       "achieved": lik_bytes / (lik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": lik_bytes / (lik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "two launches (bt->lM, b->S_B) timed together with HIP events"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as CO
+        cores = CO.max_threads()
+        n_c = args.cpu_chains or max(cores, 8)
+        S_B = fit._d["S_B"].cpu().numpy()
+        lM = fit._d["lM"].cpu().numpy()
+        lng, lnpi2 = np.log(model.gamma), np.log(model.pi2())
+        f_o, r_o = CO.gibbs_init(n_c, Nreg, U, float(model.pi), seed, 0)
+        CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, 0)                 # warm-up sweep
+        CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, 0, 1)
+        n_sw, t_c = 0, 0.0
+        tc0 = time.perf_counter()
+        while True:
+            n_sw += 1
+            CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, n_sw)
+            CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, n_sw, 1)
+            t_c = time.perf_counter() - tc0
+            if t_c > 10.0 or n_sw >= 50:
+                break
+        out["cpu_baseline"] = {"value": n_c * n_sw / t_c, "unit": "samples/s", "cores": cores, "kind": "port",
+                               "sample": "%d chains x %d sweeps of the same cfg3 tables with the C restatement "
+                                         "(oracle/fcdiff_oracle.c, OpenMP over chains), %.1f s" % (n_c, n_sw, t_c)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

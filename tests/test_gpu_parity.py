@@ -1,0 +1,462 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI
+(include/fcdiff_hip.h) via the Python mirror of the reference API; expected values come from
+  * fixtures captured from the reference itself (tests/golden), and
+  * the CPU oracle (oracle/), which test_oracle_golden.py / test_oracle_c.py pin to those fixtures.
+
+Tolerances (fp64): tables rtol 1e-12 (device exp/log are within a few ulp of libm's); quantities
+that sum over patients/edges rtol 1e-10; integer state (Gibbs chains, counts) bit-exact.
+"""
+import numpy as np
+import numpy.testing as nptest
+import pytest
+
+from conftest import load_golden, theta_dict
+
+pytestmark = pytest.mark.gpu
+
+TAB = dict(rtol=1e-12, atol=1e-14)
+SUM = dict(rtol=1e-10, atol=1e-11)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fcdiff_amd
+    from fcdiff_amd import _lib
+    from fcdiff_amd.gibbs import GibbsEngine
+    from oracle import c_oracle as CO
+    from oracle import fcdiff_oracle as O
+    _lib.load()
+
+    class E:
+        pass
+    e = E()
+    e.torch, e.pkg, e.lib, e.GibbsEngine, e.CO, e.O = torch, fcdiff_amd, _lib, GibbsEngine, CO, O
+    e.ctx = _lib.Context()
+    return e
+
+
+def make_model(env, theta):
+    th = theta_dict(theta)
+    m = env.pkg.UnsharedRegionModel()
+    m.pi, m.eta, m.epsilon = th["pi"], th["eta"], th["epsilon"]
+    m.gamma, m.mu, m.sigma = th["gamma"], th["mu"], th["sigma"]
+    return m
+
+
+def new_fit(env):
+    f = env.pkg.fit.UnsharedRegionFit()
+    f._ctx = env.ctx
+    return f
+
+
+def up(env, a, dtype=None):
+    return env.torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+# ------------------------------------------------------------------------------------------------
+# K_lik: UnsharedRegionFit._update_lps  (test_fcdiff/test_fit.py:131-166)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["G2_update_lps", "G2b_update_lps_default"])
+def test_update_lps_against_reference_fixture(env, name):
+    g = load_golden(name)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = g["b"], g["bt"], make_model(env, g["theta"])
+    (C, H) = g["b"].shape
+    U = g["bt"].shape[1]
+    N = int(round(env.pkg.util.C_to_N(C)))
+    fit._init_lps(N, H, U)
+    assert fit._lq_R.shape == (N, U, 2) and fit._lq_F.shape == (C, 1, 3) and fit._lM.shape == (C, U, 3, 3)
+    nptest.assert_allclose(np.sum(np.exp(fit._lq_R), axis=2), 1)
+    nptest.assert_allclose(np.sum(np.exp(fit._lq_F), axis=2), 1)
+    fit._update_lps()
+    nptest.assert_allclose(fit._lM, g["lM"], **TAB)
+    nptest.assert_allclose(fit._lp_B_g_F, g["lp_B_g_F"], **TAB)
+    nptest.assert_allclose(fit._p_Bt_g_Ft, g["p_Bt_g_Ft"], rtol=1e-12, atol=0)
+    nptest.assert_allclose(fit._d["S_B"].cpu().numpy(), g["lp_B_g_F"].sum(axis=1), rtol=1e-12)
+    assert fit._lp_B_g_F.shape == (C, H, 3) and fit._p_Bt_g_Ft.shape == (C, U, 3)
+
+
+@pytest.mark.parametrize("N,H,U", [(2, 1, 1), (3, 1, 70), (9, 17, 1), (23, 16, 37), (40, 3, 129)])
+def test_lik_tables_ragged_shapes(env, N, H, U):
+    """Sizes that are not multiples of the 256-item tile / 16-lane groups, against the C oracle."""
+    m = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=N + U)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    S_B, lM = env.CO.lik_tables(b, bt, m.theta())
+    nptest.assert_allclose(fit._lM, lM, **TAB)
+    nptest.assert_allclose(fit._d["S_B"].cpu().numpy(), S_B, rtol=1e-12)
+
+
+def test_lik_tables_underflow_gives_minus_inf_like_reference(env):
+    """The reference forms M from linear-space densities (fit.py:115,121-122): |z| > 38.6 underflows."""
+    m = env.pkg.UnsharedRegionModel()
+    m.sigma = np.array([1e-3, 1e-3, 1e-3])
+    b = np.zeros((3, 2))
+    bt = np.array([[1.0, -1.0], [0.0, 0.3], [-0.15, 1.0]])
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(3, 2, 2)
+    fit._update_lps()
+    with np.errstate(divide="ignore"):
+        _, _, lM = env.O.lik_tables(b, bt, m.mu, m.sigma, m.eta, m.epsilon)
+    got = fit._lM
+    assert np.array_equal(np.isneginf(got), np.isneginf(lM)) and np.isneginf(lM).any()
+    fin = np.isfinite(lM)
+    nptest.assert_allclose(got[fin], lM[fin], **TAB)
+
+
+def test_lik_tables_cfg3_size(env):
+    """BASELINE cfg 3 shape (Nreg=200, H=U=50) against the C oracle."""
+    (N, H, U) = (200, 50, 50)
+    m = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=3)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    S_B, lM = env.CO.lik_tables(b, bt, m.theta())
+    nptest.assert_allclose(fit._lM, lM, **TAB)
+    nptest.assert_allclose(fit._d["S_B"].cpu().numpy(), S_B, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------
+# VB updates (test_fit.py:428-557) and energy (170-230, 389-425)
+# ------------------------------------------------------------------------------------------------
+def test_update_lq_F(env):
+    g = load_golden("G4_update_lq_F")
+    fit = new_fit(env)
+    fit._lq_R = np.log(g["q_R"])
+    fit._lp_B_g_F = g["lp_B_g_F"]
+    fit._lM = g["lM"]
+    fit.model = env.pkg.UnsharedRegionModel()
+    fit.model.gamma = g["gamma"]
+    fit._update_lq_F()
+    assert fit._lq_F.shape == g["lq_F"].shape
+    nptest.assert_allclose(fit._lq_F, g["lq_F"], **SUM)
+
+
+def test_update_lq_R_reference_and_symmetric(env):
+    g = load_golden("G5_update_lq_R")
+    for mode in ("reference", "symmetric"):
+        fit = new_fit(env)
+        fit.edge_index = mode
+        fit._lq_R = np.log(g["q_R"])
+        fit._lq_F = np.log(g["q_F"])
+        fit._lM = g["lM"]
+        fit.model = env.pkg.UnsharedRegionModel()
+        fit.model.pi = g["pi"]                      # 2-vector, as the reference's test passes it
+        fit._update_lq_R()
+        if mode == "reference":
+            nptest.assert_allclose(fit._lq_R, g["lq_R"], **SUM)
+        else:
+            exp = env.O.update_lq_R(np.log(g["q_R"]), np.log(g["q_F"]), g["lM"], g["pi"], env.O.EDGE_SYMMETRIC)
+            nptest.assert_allclose(fit._lq_R, exp, **SUM)
+
+
+def test_update_lq_R_reference_ids_need_three_regions(env):
+    fit = new_fit(env)
+    fit._lq_R = np.log(np.full((2, 3, 2), 0.5))
+    fit._lq_F = np.log(np.full((1, 1, 3), 1 / 3))
+    fit._lM = np.zeros((1, 3, 3, 3))
+    fit.model = env.pkg.UnsharedRegionModel()
+    with pytest.raises(IndexError):                 # the reference indexes _lM[1] of a size-1 axis
+        fit._update_lq_R()
+    fit.edge_index = "symmetric"
+    fit._update_lq_R()
+
+
+def test_energy_terms(env):
+    g = load_golden("G6_energy_terms")
+    fit = new_fit(env)
+    fit.model = env.pkg.UnsharedRegionModel()
+    fit.model.gamma, fit.model.pi = g["gamma"], g["pi2"]
+    fit._lq_F, fit._lq_R, fit._lp_B_g_F, fit._lM = np.log(g["q_F"]), np.log(g["q_R"]), g["lp_B_g_F"], g["lM"]
+    nptest.assert_allclose(fit._energy_terms(), g["terms"], **SUM)
+    nptest.assert_allclose(fit._eval_energy(), g["energy"], **SUM)
+    e1, e2 = fit._eval_energy(), fit._eval_energy()
+    assert e1 == e2                                 # fixed reduction order: bitwise repeatable
+
+
+def test_update_pi_gamma(env):
+    g = load_golden("G7_pi_gamma")
+    fit = new_fit(env)
+    fit.model = env.pkg.UnsharedRegionModel()
+    fit._lq_R = np.log(g["q_R"])
+    fit._update_pi()
+    nptest.assert_allclose(fit.model.pi, g["pi"], rtol=1e-13)
+    assert np.ndim(fit.model.pi) == 0
+    fit2 = new_fit(env)
+    fit2.model = env.pkg.UnsharedRegionModel()
+    fit2._lq_F = np.log(g["q_F"])
+    fit2._update_gamma()
+    nptest.assert_allclose(fit2.model.gamma, g["gamma"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("name,iters", [("G10_vb_trajectory_cfg1", 4), ("G10b_vb_trajectory_cfg1_ideal", 4),
+                                        ("G12_vb_trajectory_mid", 3)])
+def test_run_reproduces_reference_vb_trajectory(env, name, iters):
+    """run() = the documented loop; energies, q's, pi, gamma after each iteration vs the reference's."""
+    g = load_golden(name)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = g["b"], g["bt"], make_model(env, g["theta0"])
+    fit.max_iters = iters
+    fit.rel_tol = -np.inf                            # never 'converged': record the whole trajectory
+    fit.run()
+    assert len(fit.energy) == iters + 1
+    nptest.assert_allclose(fit.energy, g["energy"], rtol=1e-10)
+    nptest.assert_allclose(fit._lq_F, g["lq_F"][iters - 1], rtol=1e-8, atol=1e-10)
+    nptest.assert_allclose(fit._lq_R, g["lq_R"][iters - 1], rtol=1e-8, atol=1e-10)
+    nptest.assert_allclose(fit.model.pi, g["pi"][iters], rtol=1e-10)
+    nptest.assert_allclose(fit.model.gamma, g["gamma"][iters], rtol=1e-10)
+
+
+def test_run_convergence_and_errors(env):
+    g = load_golden("G10_vb_trajectory_cfg1")
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = g["b"], g["bt"], make_model(env, g["theta0"])
+    fit.run()                                        # defaults: max_iters 10, rel_tol 1e-5
+    # quirk Q6: e0 > 0 so the first decrease does not stop; e1 < 0 so the next one does (fit.py:138-140)
+    assert len(fit.energy) == 3
+    nptest.assert_allclose(fit.energy, g["energy"][:3], rtol=1e-10)
+    bad = new_fit(env)
+    bad.b, bad.bt, bad.model = np.zeros((7, 2)), np.zeros((7, 3)), make_model(env, g["theta0"])
+    with pytest.raises(ValueError, match=r"Number of connections \(7\) must be a triangular number."):
+        bad.run()
+    nomodel = new_fit(env)
+    nomodel.b, nomodel.bt = g["b"], g["bt"]
+    with pytest.raises(ValueError, match="Model has not been initialized."):
+        nomodel.run()
+
+
+def test_is_converged_cases(env):
+    """test_fit.py:86-129."""
+    for (e, expect) in (([1, 1.25], True), ([1, 1], True), ([1, 0.501], True), ([1, 0.5], False), ([1, 0.499], False)):
+        fit = env.pkg.fit.UnsharedRegionFit()
+        fit.rel_tol = 0.5
+        fit.energy = e
+        assert bool(fit._is_converged(1)) is expect
+
+
+def test_vb_iteration_cfg2_size_against_c_oracle(env):
+    """BASELINE cfg 2 shape (Nreg=64, H=U=16): one full iteration against the C oracle."""
+    (N, H, U) = (64, 16, 16)
+    m = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=2)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    S_B, lM = env.CO.lik_tables(b, bt, m.theta())
+    lq_R0 = fit._lq_R
+    fit._update_lq_F()
+    lq_F = env.CO.update_lq_F(lq_R0, S_B, lM, m.gamma)
+    nptest.assert_allclose(fit._lq_F, lq_F, rtol=1e-9, atol=1e-10)
+    fit._update_lq_R()
+    lq_R = env.CO.update_lq_R(lq_R0, lq_F, lM, m.pi2(), 0)
+    nptest.assert_allclose(fit._lq_R, lq_R, rtol=1e-9, atol=1e-10)
+    t = env.CO.energy_terms(lq_F, lq_R, S_B, lM, m.gamma, m.pi2())
+    nptest.assert_allclose(fit._energy_terms(), t, rtol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# Gibbs sampler
+# ------------------------------------------------------------------------------------------------
+def tables_for(env, N, H, U, seed, ideal=False):
+    m = env.pkg.UnsharedRegionModel()
+    if ideal:
+        m.pi, m.epsilon, m.eta = 0.1, 0.01, 0.3
+        m.gamma, m.mu, m.sigma = np.ones(3) / 3, np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=seed)
+    S_B, lM = env.CO.lik_tables(b, bt, m.theta())
+    return m, S_B, lM
+
+
+def test_philox_device_equals_oracle(env):
+    rs = np.random.RandomState(0)
+    ctr = rs.randint(0, 2 ** 32, size=(257, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[0] = 0
+    ctr[1] = 0xFFFFFFFF
+    seed = 0xA4093822299F31D0
+    out = env.torch.empty(257 * 2, dtype=env.torch.float64, device="cuda")
+    import ctypes
+    env.ctx.call("fcd_philox_uniforms", env.lib.dptr(up(env, ctr)), 257, ctypes.c_uint64(seed), env.lib.dptr(out),
+                 env.lib.stream_ptr())
+    got = out.cpu().numpy().reshape(257, 2)
+    for i in range(257):
+        for half in range(2):
+            assert got[i, half] == env.O.site_uniform(seed, ctr[i, 0], ctr[i, 1], ctr[i, 2], ctr[i, 3], half)
+    assert (got >= 0).all() and (got < 1).all()
+
+
+@pytest.mark.parametrize("N,U,G,chain0,mode", [(10, 4, 64, 0, "symmetric"), (10, 4, 100, 7, "reference"),
+                                                (13, 7, 130, 64, "symmetric"), (5, 1, 1, 0, "symmetric"),
+                                                (3, 9, 65, 1, "reference"), (24, 70, 192, 5, "symmetric")])
+def test_gibbs_chains_equal_oracle_state_for_state(env, N, U, G, chain0, mode):
+    """init + 3 sweeps: every f_c and r_nu of every chain equals the C oracle's (same Philox counters)."""
+    (m, S_B, lM) = tables_for(env, N, 5, U, seed=N * 100 + U)
+    seed = 0x0123456789ABCDEF + N
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=chain0, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.25)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.25, seed, chain0)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    emode = env.lib.EDGE_MODES[mode]
+    for s in range(3):
+        eng.f_step(s)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, chain0)
+        f_g, _ = eng.export_state()
+        nptest.assert_array_equal(f_g, f_o)
+        eng.r_step(s)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, emode, chain0)
+        _, r_g = eng.export_state()
+        nptest.assert_array_equal(r_g, r_o)
+    nptest.assert_array_equal(eng.stats().cpu().numpy()[:5], env.CO.gibbs_stats(f_o, r_o)[:5])
+    nptest.assert_allclose(eng.logjoint().cpu().numpy(), env.CO.gibbs_logjoint(f_o, r_o, S_B, lM, lng, lnpi2), rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "mid"])
+def test_gibbs_conditionals_against_reference_pins(env, tag):
+    """Device conditionals at the fixture's state vs the reference's own one-hot evaluations (G11)."""
+    g = load_golden("G11_gibbs_conditionals_" + tag)
+    m = make_model(env, g["theta"])
+    S_B = g["lp_B_g_F"].sum(axis=1)
+    (N, U) = g["r_state"].shape
+    G = 3
+    f = np.tile(g["f_state"][None], (G, 1))
+    r = np.tile(g["r_state"][None], (G, 1, 1))
+    for mode in ("reference", "symmetric"):
+        eng = env.GibbsEngine(up(env, S_B), up(env, g["lM"]), N, U, G, edge_index=mode, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.import_state(f, r)
+        f2, r2 = eng.export_state()
+        nptest.assert_array_equal(f2, f)
+        nptest.assert_array_equal(r2, r)
+        cf, cr = eng.conditionals()
+        cf, cr = cf.cpu().numpy(), cr.cpu().numpy()
+        for gi in range(G):
+            a = cf[gi] - env.O.logsumexp(cf[gi], axis=1)
+            nptest.assert_allclose(a, g["cond_f"][:, 0, :], rtol=1e-10, atol=1e-10)       # fit.py:157-174
+            if mode == "reference":
+                row0 = cr[gi, 0] - env.O.logsumexp(cr[gi, 0], axis=1)
+                nptest.assert_allclose(row0, g["lq_R_after_update"][0], rtol=1e-10, atol=1e-10)  # fit.py:176-198
+            else:
+                nptest.assert_allclose(cr[gi, :, :, 1] - cr[gi, :, :, 0],
+                                       g["logjoint_r"][:, :, 1] - g["logjoint_r"][:, :, 0], rtol=1e-8, atol=1e-8)
+        nptest.assert_allclose(eng.logjoint().cpu().numpy(), np.full(G, g["logjoint_base"]), rtol=1e-12)
+
+
+def test_gibbs_chain_sharding_invariance(env):
+    """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
+    (N, U, G) = (12, 6, 192)
+    (m, S_B, lM) = tables_for(env, N, 4, U, seed=5)
+    outs = []
+    for (c0, g) in ((0, 192), (0, 96), (96, 96)):
+        eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, g, chain0=c0, seed=11, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.1)
+        eng.sweeps(0, 4)
+        outs.append(eng.export_state())
+    nptest.assert_array_equal(outs[0][0], np.concatenate([outs[1][0], outs[2][0]]))
+    nptest.assert_array_equal(outs[0][1], np.concatenate([outs[1][1], outs[2][1]]))
+
+
+def test_gibbs_mstep_and_accumulate(env):
+    (N, U, G) = (9, 5, 70)
+    (m, S_B, lM) = tables_for(env, N, 4, U, seed=8, ideal=True)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, seed=3, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    cf = np.zeros((eng.C, 3), dtype=np.int64)
+    cr = np.zeros((N, U), dtype=np.int64)
+    for s in range(3):
+        eng.sweeps(s, 1)
+        eng.accumulate()
+        f, r = eng.export_state()
+        for k in range(3):
+            cf[:, k] += (f == k).sum(axis=0)
+        cr += r.sum(axis=0)
+    nptest.assert_array_equal(eng.cnt_f.cpu().numpy(), cf)
+    nptest.assert_array_equal(eng.cnt_r.cpu().numpy(), cr)
+    counts = eng.stats()
+    c = counts.cpu().numpy()
+    assert c[4] == G and c[1] + c[2] + c[3] == G * eng.C and c[0] == r.sum()
+    eng.mstep(counts)
+    (gamma, pi) = eng.hyper_values()
+    from fcdiff_amd.gibbs import mstep_from_counts
+    (pi_h, gamma_h) = mstep_from_counts(c, N, U)
+    nptest.assert_allclose(pi, pi_h, rtol=1e-14)                 # fit.py:213 over chains
+    nptest.assert_allclose(gamma, gamma_h, rtol=1e-14)           # fit.py:220 over chains
+    nptest.assert_allclose(pi, r.mean(), rtol=1e-14)
+
+
+def test_fit_gibbs_recovers_planted_structure(env):
+    """End to end through UnsharedRegionFit(method='gibbs') on well separated synthetic data."""
+    (N, H, U) = (16, 8, 8)
+    gen = env.pkg.UnsharedRegionModel()
+    gen.pi, gen.epsilon, gen.eta = 0.1, 0.01, 0.3
+    gen.gamma, gen.mu, gen.sigma = np.ones(3) / 3, np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (r, t, f, ft, b, bt) = gen.sample_fast(N, H, U, seed=4)
+    fit = new_fit(env)
+    fit.method = "gibbs"
+    fit.model = make_model(env, gen.theta())
+    fit.b, fit.bt = b, bt
+    fit.n_chains, fit.n_sweeps, fit.burn_in, fit.energy_every = 128, 40, 10, 10
+    fit.run()
+    assert fit._lq_F.shape == (N * (N - 1) // 2, 1, 3) and fit._lq_R.shape == (N, U, 2)
+    assert (np.argmax(fit._lq_F[:, 0, :], axis=1) == np.argmax(f, axis=1)).mean() > 0.98
+    assert ((np.exp(fit._lq_R[:, :, 1]) > 0.5) == r).mean() > 0.9
+    assert len(fit.energy) == 4 and np.all(np.isfinite(fit.energy))
+    assert 0 < fit.model.pi < 0.5 and abs(np.sum(fit.model.gamma) - 1) < 1e-12
+    # and the variational fit of the same data agrees on the template
+    vb = new_fit(env)
+    vb.model, vb.b, vb.bt, vb.edge_index = make_model(env, gen.theta()), b, bt, "symmetric"
+    vb.rel_tol = -np.inf
+    vb.run()
+    assert (np.argmax(vb._lq_F[:, 0, :], axis=1) == np.argmax(fit._lq_F[:, 0, :], axis=1)).mean() > 0.98
+
+
+def test_gibbs_cfg3_size_properties(env):
+    """
+    BASELINE cfg 3 shape (Nreg=200, H=U=50), 1024 chains: size-independent properties --
+    the first chains equal the C oracle state for state, a re-run is bitwise identical, a shard equals the
+    matching slice of the full run, pooled counts equal a recount of the exported state.
+    """
+    (N, H, U, G) = (200, 50, 50, 1024)
+    (m, S_B, lM) = tables_for(env, N, H, U, seed=33)
+    S_B_d, lM_d = up(env, S_B), up(env, lM)
+    seed = 2024
+
+    def run(c0, g):
+        eng = env.GibbsEngine(S_B_d, lM_d, N, U, g, chain0=c0, seed=seed, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.05)
+        eng.sweeps(0, 2)
+        return eng
+    full = run(0, G)
+    f_g, r_g = full.export_state()
+    again = run(0, G).export_state()
+    assert np.array_equal(f_g, again[0]) and np.array_equal(r_g, again[1])
+    shard = run(640, 128).export_state()
+    assert np.array_equal(f_g[640:768], shard[0]) and np.array_equal(r_g[640:768], shard[1])
+    c = full.stats().cpu().numpy()
+    assert c[0] == r_g.sum() and [c[1], c[2], c[3]] == [(f_g == k).sum() for k in range(3)] and c[4] == G
+    # oracle: chains 0..3 and 1020..1023
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for c0 in (0, 1020):
+        f_o, r_o = env.CO.gibbs_init(4, N, U, 0.05, seed, c0)
+        for s in range(2):
+            env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, c0)
+            env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, 1, c0)
+        assert np.array_equal(f_g[c0:c0 + 4], f_o) and np.array_equal(r_g[c0:c0 + 4], r_o)
+    lj = full.logjoint().cpu().numpy()
+    nptest.assert_allclose(lj[:4], env.CO.gibbs_logjoint(f_g[:4].copy(), r_g[:4].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
