@@ -47,8 +47,9 @@ SIGNATURES = {
     "fcd_gibbs_state_size": (_int, [_i64, _i64, _i64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fcd_gibbs_init": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _u64, _dbl, _p]),
     "fcd_gibbs_f_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _p]),
-    "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
-    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
+    "fcd_gibbs_region_tables": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
+    "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
+    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
     "fcd_gibbs_stats": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "fcd_gibbs_mstep": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "fcd_gibbs_accumulate": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
@@ -75,6 +76,10 @@ def load():
         raise ImportError(
             "fcdiff_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C fcdiff_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries the HIP runtime (libamdhip64.so.7) every tensor and stream of this
+    # process lives in; loaded afterwards, our library binds to that same runtime by soname.  The other
+    # order leaves two runtimes in the process and ours then sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol

@@ -133,3 +133,31 @@ __device__ static inline uint32_t fcd_sel_mask(uint32_t a, uint32_t b, uint64_t 
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
     return out;
 }
+
+// mask of the chains of word w that exist (the last word of G chains may be partial)
+__host__ __device__ static inline uint64_t fcd_active_mask(int w, int64_t G) {
+    const int64_t rem = G - (int64_t)w * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: shape checks shared by the sampler entry points
+// ---------------------------------------------------------------------------------------------
+struct fcd_geo {
+    int64_t C;
+    int GW;
+};
+
+static inline int fcd_geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, fcd_geo &g) {
+    if (!ctx) return FCD_ERR_ARG;
+    if (Nreg < 2 || U < 1 || G < 1)
+        return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2, U >= 1, G >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
+    if (Nreg > 46340 || U > (1 << 20) || G > (1ll << 31) || chain0 < 0 || chain0 + G > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "shape out of range (Nreg=%lld, G=%lld)", Nreg, G);
+    g.C = fcd_tri(Nreg);
+    g.GW = (int)((G + 63) / 64);
+    if (g.GW > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "G=%lld exceeds 65535 chain words per launch", G);
+    if ((Nreg + 1) / 2 * U > (1ll << 32) || (g.C + 1) / 2 > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "site index exceeds the 32-bit counter word");
+    return FCD_OK;
+}

@@ -14,11 +14,6 @@
 
 namespace {
 
-__device__ inline uint64_t active_mask(int w, int64_t G) {
-    const int64_t rem = G - (int64_t)w * 64;
-    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-}
-
 // ---------------------------------------------------------------------------------------------
 // init
 // ---------------------------------------------------------------------------------------------
@@ -142,68 +137,6 @@ __global__ __launch_bounds__(1024) void gibbs_f_kernel(const double *__restrict_
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// r step, version 1.  grid = (U, GW): one block per (patient, chain word); regions strictly in order
-// (systematic scan), the four waves split the sum over the other region m.  The 64 chains' r_mu is a
-// uint64 kept in LDS (mask[m]) and refreshed by ballot after each region.
-// ---------------------------------------------------------------------------------------------
-constexpr int R_WAVES = 4;
-__global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
-                                                               const uint8_t *__restrict__ f_state,
-                                                               uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
-                                                               uint32_t chain0, uint64_t seed, uint32_t sweep, int mode) {
-    extern __shared__ uint64_t sh_r[];
-    uint64_t *mask = sh_r;                                         // [Nreg]
-    double *part = reinterpret_cast<double *>(sh_r + Nreg);        // [R_WAVES][2][64]
-    const int u = blockIdx.x, w = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint64_t *__restrict__ rcol = r_bits + (int64_t)w * Nreg * U + u;
-    for (int n = tid; n < Nreg; n += 64 * R_WAVES) mask[n] = rcol[(int64_t)n * U];
-    __syncthreads();
-    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C * 64 + lane;
-    const double *__restrict__ lMu = lM + (int64_t)u * 9;
-    const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
-    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    fcd_u4 rnd = {0, 0, 0, 0};
-
-    for (int n = 0; n < Nreg; ++n) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll 4
-        for (int m = wave; m < Nreg; m += R_WAVES) {
-            const bool valid = (m != n);
-            const int64_t c = valid ? fcd_pair_to_edge(n, m, mode) : 0;
-            const int k = fw[c * 64];
-            const uint32_t bit = (uint32_t)((mask[m] >> lane) & 1ull);
-            const double *p = lMu + (c * U) * 9 + k * 3;
-            // r_m = 0: (lM[k,0], lM[k,2]);  r_m = 1: (lM[k,2], lM[k,1])      fit.py:188-194
-            const double v0 = p[bit * 2];
-            const double v1 = p[2 - bit];
-            s0 += valid ? v0 : 0.0;
-            s1 += valid ? v1 : 0.0;
-        }
-        part[(wave * 2 + 0) * 64 + lane] = s0;
-        part[(wave * 2 + 1) * 64 + lane] = s1;
-        __syncthreads();
-        if (wave == 0) {
-            double t0 = part[0 * 64 + lane], t1 = part[1 * 64 + lane];
-#pragma unroll
-            for (int j = 1; j < R_WAVES; ++j) {
-                t0 += part[(j * 2 + 0) * 64 + lane];
-                t1 += part[(j * 2 + 1) * 64 + lane];
-            }
-            if ((n & 1) == 0)
-                rnd = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
-            const double x = (n & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
-            const uint64_t ball = __ballot(fcd_draw_r(lnpi0 + t0, lnpi1 + t1, x));
-            if (lane == 0) mask[n] = ball;
-        }
-        __syncthreads();
-    }
-    for (int n = tid; n < Nreg; n += 64 * R_WAVES) rcol[(int64_t)n * U] = mask[n];
-}
-
 // conditional log-weights of every r site given the CURRENT state (nothing updated): parity hook.
 __global__ __launch_bounds__(64) void gibbs_cond_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
                                                           const uint8_t *__restrict__ f_state,
@@ -242,7 +175,7 @@ __global__ __launch_bounds__(256) void gibbs_stats_kernel(const uint8_t *__restr
     const int64_t rows = (int64_t)GW * C;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const int w = (int)(row / C);
-        const uint64_t act = active_mask(w, G);
+        const uint64_t act = fcd_active_mask(w, G);
         const int f = f_state[row * 64 + lane];
         const uint64_t b0 = __ballot(f == 0) & act, b1 = __ballot(f == 1) & act, b2 = __ballot(f == 2) & act;
         if (lane == 0) {
@@ -255,7 +188,7 @@ __global__ __launch_bounds__(256) void gibbs_stats_kernel(const uint8_t *__restr
     const int64_t words = (int64_t)GW * NU;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(i / NU);
-        cr += __popcll(r_bits[i] & active_mask(w, G));
+        cr += __popcll(r_bits[i] & fcd_active_mask(w, G));
     }
     // integer sums: any order gives the same result
     for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
@@ -294,7 +227,7 @@ __global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restr
     for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < C; c += (int64_t)gridDim.x * 4) {
         uint32_t n0 = 0, n1 = 0, n2 = 0;
         for (int w = 0; w < GW; ++w) {
-            const uint64_t act = active_mask(w, G);
+            const uint64_t act = fcd_active_mask(w, G);
             const int f = f_state[((int64_t)w * C + c) * 64 + lane];
             n0 += __popcll(__ballot(f == 0) & act);
             n1 += __popcll(__ballot(f == 1) & act);
@@ -308,7 +241,7 @@ __global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restr
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NU; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t s = 0;
-        for (int w = 0; w < GW; ++w) s += __popcll(r_bits[(int64_t)w * NU + i] & active_mask(w, G));
+        for (int w = 0; w < GW; ++w) s += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
         cnt_r[i] += s;
     }
 }
@@ -400,25 +333,6 @@ __global__ void philox_uniforms_kernel(const uint32_t *__restrict__ ctr4, int64_
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-struct Geo {
-    int64_t C;
-    int GW;
-};
-
-int geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, Geo &g) {
-    if (!ctx) return FCD_ERR_ARG;
-    if (Nreg < 2 || U < 1 || G < 1)
-        return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2, U >= 1, G >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
-    if (Nreg > 46340 || U > (1 << 20) || G > (1ll << 31) || chain0 < 0 || chain0 + G > (1ll << 32))
-        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "shape out of range (Nreg=%lld, G=%lld)", Nreg, G);
-    g.C = fcd_tri(Nreg);
-    g.GW = (int)((G + 63) / 64);
-    if (g.GW > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "G=%lld exceeds 65535 chain words per launch", G);
-    if ((Nreg + 1) / 2 * U > (1ll << 32) || (g.C + 1) / 2 > (1ll << 32))
-        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "site index exceeds the 32-bit counter word");
-    return FCD_OK;
-}
-
 // edges per LDS tile of the f step and waves per block
 void f_step_geometry(int64_t U, int GW, int &Ec, int &wpb, size_t &shmem) {
     wpb = GW < 16 ? GW : 16;
@@ -433,7 +347,7 @@ void f_step_geometry(int64_t U, int GW, int &Ec, int &wpb, size_t &shmem) {
 
 template <bool COND>
 int launch_f(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper, uint8_t *f_state,
-             const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, const Geo &g, int64_t chain0, uint64_t seed,
+             const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, const fcd_geo &g, int64_t chain0, uint64_t seed,
              int64_t sweep, double *cond_f, hipStream_t s) {
     int Ec, wpb;
     size_t shmem;
@@ -464,8 +378,8 @@ extern "C" int fcd_gibbs_state_size(int64_t Nreg, int64_t U, int64_t G, size_t *
 
 extern "C" int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                               int64_t chain0, uint64_t seed, double pi, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
     if (!f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_init: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -483,38 +397,18 @@ extern "C" int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, 
 extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
                                 uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
     if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_f_step: null pointer");
     return launch_f<false>(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, g, chain0, seed, sweep, nullptr,
                            (hipStream_t)stream);
 }
 
-extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *hyper, const uint8_t *f_state,
-                                uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
-                                int64_t sweep, int edge_mode, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, chain0, g);
-    if (rc) return rc;
-    if (!lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: null pointer");
-    if (edge_mode != FCD_EDGE_REFERENCE && edge_mode != FCD_EDGE_SYMMETRIC)
-        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: edge_mode %lld", edge_mode);
-    if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
-        return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
-    const size_t shmem = (size_t)Nreg * 8 + (size_t)R_WAVES * 2 * 64 * 8;
-    if (shmem > 64 * 1024) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld exceeds the LDS mask array", Nreg);
-    hipLaunchKernelGGL(gibbs_r_kernel, dim3((unsigned)U, (unsigned)g.GW), dim3(64 * R_WAVES), shmem, (hipStream_t)stream,
-                       lM, hyper, f_state, r_bits, (int)Nreg, (int)U, g.C, (uint32_t)chain0, seed, (uint32_t)sweep,
-                       edge_mode);
-    FCD_LAUNCH_CHECK();
-    return FCD_OK;
-}
-
 extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
                                int64_t G, int64_t *counts, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!f_state || !r_bits || !counts) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_stats: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -528,7 +422,7 @@ extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMr, const double *hyper,
                                 uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                                 uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                                 fcd_stream stream) {
@@ -537,7 +431,7 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
     for (int64_t i = 0; i < n_sweeps; ++i) {
         int rc = fcd_gibbs_f_step(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step(ctx, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
+        rc = fcd_gibbs_r_step(ctx, lM, lMr, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
         if (rc) return rc;
     }
     if (counts && n_sweeps > 0) return fcd_gibbs_stats(ctx, f_state, r_bits, Nreg, U, G, counts, stream);
@@ -556,8 +450,8 @@ extern "C" int fcd_gibbs_mstep(fcd_ctx *ctx, const int64_t *counts, int64_t Nreg
 
 extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
                                     int64_t U, int64_t G, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!f_state || !r_bits || !cnt_f || !cnt_r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_accumulate: null pointer");
     int64_t blocks = (g.C + 3) / 4;
@@ -572,8 +466,8 @@ extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const 
 extern "C" int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
                                   const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                   double *out, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!S_B || !lM || !hyper || !f_state || !r_bits || !out) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_logjoint: null pointer");
     const size_t need = (size_t)LJ_SLICES * g.GW * 64 * sizeof(double);
@@ -592,8 +486,8 @@ extern "C" int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double 
 extern "C" int fcd_gibbs_conditionals(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
                                       const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
                                       int64_t G, int edge_mode, double *cond_f, double *cond_r, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_conditionals: null pointer");
     if (edge_mode != FCD_EDGE_REFERENCE && edge_mode != FCD_EDGE_SYMMETRIC)
@@ -616,8 +510,8 @@ extern "C" int fcd_gibbs_conditionals(fcd_ctx *ctx, const double *S_B, const dou
 
 extern "C" int fcd_gibbs_export_state(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
                                       int64_t U, int64_t G, uint8_t *f, uint8_t *r, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!f_state || !r_bits || !f || !r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_export_state: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -630,8 +524,8 @@ extern "C" int fcd_gibbs_export_state(fcd_ctx *ctx, const uint8_t *f_state, cons
 
 extern "C" int fcd_gibbs_import_state(fcd_ctx *ctx, const uint8_t *f, const uint8_t *r, int64_t Nreg, int64_t U,
                                       int64_t G, uint8_t *f_state, uint64_t *r_bits, fcd_stream stream) {
-    Geo g;
-    int rc = geo_check(ctx, Nreg, U, G, 0, g);
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
     if (rc) return rc;
     if (!f_state || !r_bits || !f || !r) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_import_state: null pointer");
     hipStream_t s = (hipStream_t)stream;

@@ -295,14 +295,19 @@ def test_philox_device_equals_oracle(env):
     assert (got >= 0).all() and (got < 1).all()
 
 
+@pytest.mark.parametrize("blocked", [True, False])
 @pytest.mark.parametrize("N,U,G,chain0,mode", [(10, 4, 64, 0, "symmetric"), (10, 4, 100, 7, "reference"),
                                                 (13, 7, 130, 64, "symmetric"), (5, 1, 1, 0, "symmetric"),
-                                                (3, 9, 65, 1, "reference"), (24, 70, 192, 5, "symmetric")])
-def test_gibbs_chains_equal_oracle_state_for_state(env, N, U, G, chain0, mode):
-    """init + 3 sweeps: every f_c and r_nu of every chain equals the C oracle's (same Philox counters)."""
+                                                (3, 9, 65, 1, "reference"), (24, 70, 192, 5, "symmetric"),
+                                                (2, 3, 64, 0, "symmetric"), (33, 5, 70, 2, "reference"),
+                                                (35, 6, 128, 9, "symmetric"), (16, 2, 64, 0, "reference")])
+def test_gibbs_chains_equal_oracle_state_for_state(env, N, U, G, chain0, mode, blocked):
+    """init + 3 sweeps: every f_c and r_nu of every chain equals the C oracle's (same Philox counters).
+    blocked = the panel/diagonal r pass over the region-major table; otherwise the generic r kernel."""
     (m, S_B, lM) = tables_for(env, N, 5, U, seed=N * 100 + U)
     seed = 0x0123456789ABCDEF + N
-    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=chain0, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=chain0, seed=seed, edge_index=mode, ctx=env.ctx,
+                          region_major=blocked)
     eng.set_hyper(m.gamma, m.pi2())
     eng.init(0.25)
     f_o, r_o = env.CO.gibbs_init(G, N, U, 0.25, seed, chain0)
@@ -384,7 +389,7 @@ def test_gibbs_mstep_and_accumulate(env):
         f, r = eng.export_state()
         for k in range(3):
             cf[:, k] += (f == k).sum(axis=0)
-        cr += r.sum(axis=0)
+        cr += r.sum(axis=0, dtype=np.int64)
     nptest.assert_array_equal(eng.cnt_f.cpu().numpy(), cf)
     nptest.assert_array_equal(eng.cnt_r.cpu().numpy(), cr)
     counts = eng.stats()
