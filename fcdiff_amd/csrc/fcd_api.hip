@@ -72,7 +72,10 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
     size_t need = (size_t)64 * GW * 64 * sizeof(double);        // log-joint partials
     const size_t en = (size_t)ctx->num_cu * 8 * 8 * sizeof(double);  // energy partials
     if (en > need) need = en;
-    const size_t panel = (size_t)GW * U * 16 * 2 * 64 * sizeof(double);  // r step: per-block partial sums
+    const int64_t NBLK = (Nreg + 15) / 16;
+    const size_t panel = (size_t)GW * U * 16 * 64 * sizeof(double)         // r step: per-block partial sums,
+                         + (size_t)GW * Nreg * NBLK * 64 * 4                // packed f,
+                         + (size_t)GW * U * NBLK * 64 * 2 + 512;            // per-lane r words
     if (panel > need) need = panel;
     return fcd_ws_reserve(ctx, need);
 }

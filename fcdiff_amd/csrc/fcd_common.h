@@ -112,10 +112,10 @@ __device__ static inline int fcd_draw_f(double a0, double a1, double a2, double 
     return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
 }
 
-__device__ static inline int fcd_draw_r(double s0, double s1, double x) {
-    double p1 = 1.0 / (1.0 + exp(s0 - s1));
-    return x < p1 ? 1 : 0;
-}
+// r = 1 with probability sigmoid(s1 - s0):  x < 1/(1+exp(s0-s1))  <=>  logit(x) < s1 - s0.
+// The threshold depends on the random number only, so it is computed off the region-to-region chain.
+__device__ static inline double fcd_logit(double x) { return log(x / (1.0 - x)); }
+__device__ static inline int fcd_draw_r(double s0, double s1, double x) { return fcd_logit(x) < (s1 - s0) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers

@@ -422,7 +422,7 @@ extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMr, const double *hyper,
+extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMd, const double *hyper,
                                 uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                                 uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                                 fcd_stream stream) {
@@ -431,7 +431,7 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
     for (int64_t i = 0; i < n_sweeps; ++i) {
         int rc = fcd_gibbs_f_step(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step(ctx, lM, lMr, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
+        rc = fcd_gibbs_r_step(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
         if (rc) return rc;
     }
     if (counts && n_sweeps > 0) return fcd_gibbs_stats(ctx, f_state, r_bits, Nreg, U, G, counts, stream);

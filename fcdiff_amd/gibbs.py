@@ -76,16 +76,16 @@ class GibbsEngine(object):
         self.cnt_r = torch.zeros((self.Nreg, self.U), dtype=torch.int32, device=dev)
         self.n_accumulated = 0
         self.ctx.call("fcd_ctx_reserve", self.Nreg, self.U, self.G)
-        self.lMr = None
+        self.lMd = None
         if region_major:
-            self.lMr = torch.empty((self.U, self.Nreg, self.Nreg, 3, 3), dtype=torch.float64, device=dev)
+            self.lMd = torch.empty((self.U, self.Nreg, self.Nreg, 3, 2), dtype=torch.float64, device=dev)
             self.refresh_tables()
 
     def refresh_tables(self):
         """Re-derive the region-major table after lM changed (a table build = a theta_sub change)."""
-        if self.lMr is not None:
+        if self.lMd is not None:
             self.ctx.call("fcd_gibbs_region_tables", _lib.dptr(self.lM), self.Nreg, self.U, self.edge_mode,
-                          _lib.dptr(self.lMr), _lib.stream_ptr())
+                          _lib.dptr(self.lMd), _lib.stream_ptr())
 
     # ---- hyper-parameters ----
     def set_hyper(self, gamma, pi2):
@@ -126,12 +126,12 @@ class GibbsEngine(object):
                       C.c_uint64(self.seed), int(sweep), _lib.stream_ptr())
 
     def r_step(self, sweep):
-        self.ctx.call("fcd_gibbs_r_step", _lib.dptr(self.lM), _lib.dptr(self.lMr), _lib.dptr(self.hyper), _lib.dptr(self.f_state),
+        self.ctx.call("fcd_gibbs_r_step", _lib.dptr(self.lM), _lib.dptr(self.lMd), _lib.dptr(self.hyper), _lib.dptr(self.f_state),
                       _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0, C.c_uint64(self.seed),
                       int(sweep), self.edge_mode, _lib.stream_ptr())
 
     def sweeps(self, sweep0, n_sweeps, with_counts=False):
-        self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMr), _lib.dptr(self.hyper),
+        self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMd), _lib.dptr(self.hyper),
                       _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
                       C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode,
                       _lib.dptr(self.counts if with_counts else None), _lib.stream_ptr())

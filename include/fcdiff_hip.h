@@ -121,21 +121,23 @@ int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, int64_t Nre
 int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
                      uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                      int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream);
-/* Region-major copy of the mixture table for the r step: lMr (U, Nreg, Nreg, 3, 3) with
- * lMr[u][n][m] = lM[edge(n, m)][u], edge() = the ordered-pair edge id of `edge_mode` (zeros at m == n).
- * Built once per table build; 8*9*U*Nreg*Nreg bytes. */
-int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMr,
+/* Region-major DIFFERENCE table for the r step: lMd (U, Nreg, Nreg, 3, 2),
+ *   lMd[u][n][m][k][t] = t ? lM[c,u,k,1] - lM[c,u,k,2] : lM[c,u,k,2] - lM[c,u,k,0],  c = edge(n, m),
+ * the contribution of region m (state t) to s1 - s0 of fit.py:187-194 when f_c = k; edge() = the
+ * ordered-pair edge id of `edge_mode` (zeros at m == n).  Built once per table build; 48*U*Nreg*Nreg bytes. */
+int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMd,
                             fcd_stream stream);
 /* Redraw every r_nu of every chain given f, regions in order 0..Nreg-1 (systematic scan; patients
- * and chains in parallel).  With lMr (made with the SAME edge_mode) the blocked path runs: panel kernels
- * stream lMr rows through LDS, small diagonal kernels resolve the in-order dependence.  lMr == NULL
+ * and chains in parallel).  With lMd (made with the SAME edge_mode) the blocked path runs: panel kernels
+ * stream lMd rows through LDS, small diagonal kernels resolve the in-order dependence (only s1 - s0
+ * is formed, as a sum of table differences: same conditional, one add per term).  lMd == NULL
  * selects the generic kernel that gathers from lM directly (any shape, much slower). */
-int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMr, const double *hyper,
+int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                      const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                      int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream);
 /* n_sweeps x (f step, r step), sweeps numbered sweep0, sweep0+1, ...  When counts != NULL the pooled
  * statistics of the LAST sweep are stored there (see fcd_gibbs_stats). */
-int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMr, const double *hyper,
+int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMd, const double *hyper,
                      uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                      uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                      fcd_stream stream);

@@ -295,8 +295,8 @@ void oracle_gibbs_r_step(const uint8_t *f, uint8_t *r, const double *lM, const d
                 if (draw) {
                     const double x = site_uniform(seed, (uint32_t)((n >> 1) * U + u), (uint32_t)(chain0 + g),
                                                   (uint32_t)sweep, KIND_R, n & 1);
-                    const double p1 = 1.0 / (1.0 + exp(s0 - s1));
-                    rg[n * U + u] = x < p1;
+                    /* r = 1 w.p. sigmoid(s1 - s0): logit(x) < s1 - s0 */
+                    rg[n * U + u] = log(x / (1.0 - x)) < (s1 - s0);
                 }
             }
         }

@@ -539,9 +539,10 @@ def draw_f(a, x):
 
 
 def draw_r(s0, s1, x):
-    with np.errstate(over="ignore"):
-        p1 = 1.0 / (1.0 + np.exp(s0 - s1))
-    return 1 if x < p1 else 0
+    """r = 1 with probability sigmoid(s1 - s0): logit(x) < s1 - s0 (same inequality as x < 1/(1+exp(s0-s1)))."""
+    with np.errstate(divide="ignore"):
+        t = np.log(x / (1.0 - x))
+    return 1 if t < (s1 - s0) else 0
 
 
 def gibbs_f_step(f, r, S_B, lM, lngamma, seed, sweep, chain0=0):
