@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcdiff_hip.so")
+# FCDIFF_HIP_LIB: load another build of the same ABI (the ablation variant of csrc/Makefile, for kernel timing only)
+LIB_PATH = os.environ.get("FCDIFF_HIP_LIB") or os.path.join(_HERE, "libfcdiff_hip.so")
 
 FCD_OK = 0
 FCD_ERR_ARG = -1
@@ -46,10 +47,11 @@ SIGNATURES = {
     "fcd_vb_theta_step": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
     "fcd_gibbs_state_size": (_int, [_i64, _i64, _i64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fcd_gibbs_init": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _u64, _dbl, _p]),
-    "fcd_gibbs_f_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _p]),
+    "fcd_gibbs_edge_tables": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "fcd_gibbs_f_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _p]),
     "fcd_gibbs_region_tables": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
     "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
-    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
+    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
     "fcd_gibbs_stats": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "fcd_gibbs_mstep": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "fcd_gibbs_accumulate": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),

@@ -3,6 +3,18 @@
 
 #include "fcd_common.h"
 
+#ifdef FCD_ABLATE
+#include <stdlib.h>
+__device__ int fcd_abl_level[4];
+void fcd_abl_refresh(hipStream_t s) {
+    int v[4] = {0, 0, 0, 0};
+    if (const char *e = getenv("FCD_ABL_F")) v[0] = atoi(e);
+    if (const char *e = getenv("FCD_ABL_PANEL")) v[1] = atoi(e);
+    if (const char *e = getenv("FCD_ABL_DIAG")) v[2] = atoi(e);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(fcd_abl_level), v, sizeof(v), 0, hipMemcpyHostToDevice, s);
+}
+#endif
+
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return FCD_OK;
     // grow: the old block may still be in use by kernels already queued, so drain first

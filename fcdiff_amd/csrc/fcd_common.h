@@ -161,3 +161,17 @@ static inline int fcd_geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "site index exceeds the 32-bit counter word");
     return FCD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ablation build (make ABLATE=1 -> libfcdiff_hip_abl.so, NEVER the product library): kernels read a level
+// from device memory and skip parts of their work so that phases can be timed A/B in one process.
+// Results are wrong whenever the level is non-zero.  In the product build FCD_ABL(x) folds to false.
+// ---------------------------------------------------------------------------------------------
+#ifdef FCD_ABLATE
+extern __device__ int fcd_abl_level[4];   // [0] f kernel, [1] panel, [2] diag
+#define FCD_ABL(slot, lvl) (fcd_abl_level[slot] >= (lvl))
+void fcd_abl_refresh(hipStream_t s);
+#else
+#define FCD_ABL(slot, lvl) false
+static inline void fcd_abl_refresh(hipStream_t) {}
+#endif

@@ -137,6 +137,93 @@ __global__ __launch_bounds__(1024) void gibbs_f_kernel(const double *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f step, difference form.  Only the two log-odds b_k = a_k - a_0, k = 1, 2 enter the draw, and
+//   b_k = ln(gamma_k/gamma_0) + (S_B[c,k] - S_B[c,0]) + sum_u lMf[c,u,l_u,k-1],
+//   lMf[c,u,l,k-1] = lM[c,u,k,l] - lM[c,u,0,l]            (edge-major difference table, 48 B per (c,u))
+// so a term is one 16-byte LDS read and two fp64 adds.  Same tiling as gibbs_f_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_tables_kernel(const double *__restrict__ lM, int64_t n_items,
+                                                          double *__restrict__ lMf) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        const double *p = lM + i * 9;
+        double *o = lMf + i * 6;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            o[l * 2 + 0] = p[3 + l] - p[l];
+            o[l * 2 + 1] = p[6 + l] - p[l];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
+                                                            const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
+                                                            const uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
+                                                            int GW, int Ec, uint32_t chain0, uint64_t seed, uint32_t sweep) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // [Ec][U][3][2]
+    const int64_t c0 = (int64_t)blockIdx.x * Ec;
+    const int ne = (int)((C - c0 < Ec) ? (C - c0) : Ec);
+    {
+        const int n_d2 = ne * U * 3;
+        const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        double2 *dst = reinterpret_cast<double2 *>(tile);
+        for (int i = threadIdx.x; i < n_d2; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (w >= GW) return;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
+    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t *__restrict__ rw = r_bits + (int64_t)w * Nreg * U;
+    fcd_u4 rnd = {0, 0, 0, 0};
+    int64_t rnd_idx = -1;
+    if (FCD_ABL(0, 3)) return;           // ablation: staging only
+
+    for (int e = 0; e < ne; ++e) {
+        const int64_t c = c0 + e;
+        int n, m;
+        fcd_edge_to_pair(c, n, m);
+        const uint64_t *__restrict__ rn = rw + (int64_t)n * U;
+        const uint64_t *__restrict__ rm = rw + (int64_t)m * U;
+        const char *tb = reinterpret_cast<const char *>(tile) + (int64_t)e * U * 48;
+        double b1 = 0.0, b2 = 0.0;
+        int u = 0;
+        for (; u + F_UNROLL <= U; u += F_UNROLL) {
+#pragma unroll
+            for (int j = 0; j < F_UNROLL; ++j) {
+                const uint64_t mn = rn[u + j], mm = rm[u + j];
+                // l = 1 (both anomalous) -> +16 B, l = 2 (discordant) -> +32 B, l = 0 -> +0 inside lMf[c,u,:,:]
+                const uint32_t off = fcd_sel_mask(fcd_sel_mask(0u, 32u, mn ^ mm), 16u, mn & mm);
+                const double2 v = *reinterpret_cast<const double2 *>(tb + (u + j) * 48 + off);
+                b1 += v.x;
+                b2 += v.y;
+            }
+        }
+        for (; u < U; ++u) {
+            const uint64_t mn = rn[u], mm = rm[u];
+            const uint32_t off = fcd_sel_mask(fcd_sel_mask(0u, 32u, mn ^ mm), 16u, mn & mm);
+            const double2 v = *reinterpret_cast<const double2 *>(tb + u * 48 + off);
+            b1 += v.x;
+            b2 += v.y;
+        }
+        b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
+        b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+        if (FCD_ABL(0, 2)) {             // ablation: no RNG / exp
+            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
+            continue;
+        }
+        if ((c >> 1) != rnd_idx) {
+            rnd_idx = c >> 1;
+            rnd = fcd_philox((uint32_t)rnd_idx, chain, sweep, FCD_KIND_F, k0, k1);
+        }
+        const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+        f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(0.0, b1, b2, x);
+    }
+}
+
 // conditional log-weights of every r site given the CURRENT state (nothing updated): parity hook.
 __global__ __launch_bounds__(64) void gibbs_cond_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
                                                           const uint8_t *__restrict__ f_state,
@@ -394,15 +481,47 @@ extern "C" int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, 
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+extern "C" int fcd_gibbs_edge_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, double *lMf,
+                                     fcd_stream stream) {
+    if (!ctx || !lM || !lMf) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_edge_tables: null pointer");
+    if (Nreg < 2 || U < 1) return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2 and U >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
+    const int64_t n_items = fcd_tri(Nreg) * U;
+    int64_t blocks = (n_items + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(edge_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lM, n_items, lMf);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                                 uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
     if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_f_step: null pointer");
-    return launch_f<false>(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, g, chain0, seed, sweep, nullptr,
-                           (hipStream_t)stream);
+    if (!lMf || (size_t)U * 48 > 160 * 1024)
+        return launch_f<false>(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, g, chain0, seed, sweep, nullptr,
+                               (hipStream_t)stream);
+    fcd_abl_refresh((hipStream_t)stream);
+    const int wpb = g.GW < 16 ? g.GW : 16;
+    const size_t per_edge = (size_t)U * 48;
+    int64_t e = (int64_t)(24 * 1024 / per_edge);
+    if (e < 1) e = 1;
+    if (e > 8) e = 8;
+    if (e > 1) e &= ~1ll;   // even: both halves of a Philox block are used inside one tile
+    const size_t shmem = per_edge * e;
+    if (shmem > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_diff_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (err != hipSuccess) return (int)err;
+    }
+    dim3 grid((unsigned)((g.C + e - 1) / e), (unsigned)((g.GW + wpb - 1) / wpb));
+    hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), shmem, (hipStream_t)stream, S_B, lMf, hyper, f_state, r_bits,
+                       (int)Nreg, (int)U, g.C, g.GW, (int)e, (uint32_t)chain0, seed, (uint32_t)sweep);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
 }
 
 extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
@@ -422,14 +541,15 @@ extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMd, const double *hyper,
+extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
+                                const double *hyper,
                                 uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                                 uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                                 fcd_stream stream) {
     if (n_sweeps < 0 || sweep0 < 0 || sweep0 + n_sweeps > (1ll << 32))
         return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_sweeps: sweep range [%lld, +%lld) outside the 32-bit counter word", sweep0, n_sweeps);
     for (int64_t i = 0; i < n_sweeps; ++i) {
-        int rc = fcd_gibbs_f_step(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
+        int rc = fcd_gibbs_f_step(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
         if (rc) return rc;
         rc = fcd_gibbs_r_step(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
         if (rc) return rc;

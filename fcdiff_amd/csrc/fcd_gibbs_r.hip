@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
 // VALU ops (bit extract, shift-add), one 8-byte LDS read and one fp64 add.
 // P[((w*U + u)*R_NB + i)][lane], i = n - 16 b_own.
 // ---------------------------------------------------------------------------------------------
+constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
 template <int UB>
 __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__ lMd, const uint32_t *__restrict__ f_r,
                                                       const uint16_t *__restrict__ r_T, double *__restrict__ P, int Nreg,
@@ -106,16 +107,16 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
     const int u0 = blockIdx.y * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
     {
-        // source rows are contiguous 16-byte (k) pairs: copy as double2, interleaving the patients
+        // source rows are contiguous 16-byte (k) pairs: copy as double2, interleaving the patients.
+        // One flat loop over (patient, element): every thread's loads are independent.
         const int row_d2 = Nreg * 3;
         double2 *dst = reinterpret_cast<double2 *>(rows);
-        for (int u = 0; u < UB; ++u) {
+        for (int it = threadIdx.x; it < UB * row_d2; it += blockDim.x) {
+            const int u = it / row_d2, i = it - u * row_d2;
             const int us = u < nu ? u : nu - 1;       // tail chunk: replicate the last patient (never stored)
             const double2 *src = reinterpret_cast<const double2 *>(lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6);
-            for (int i = threadIdx.x; i < row_d2; i += blockDim.x) {
-                const int m = i / 3, k = i - m * 3;
-                dst[(m * UB + u) * 3 + k] = src[i];
-            }
+            const int m = i / 3, k = i - m * 3;
+            dst[(m * UB + u) * 3 + k] = src[i];
         }
     }
     __syncthreads();
@@ -134,33 +135,48 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
     constexpr uint32_t REC = UB * 48u;   // bytes per region m in the tile
+    if (FCD_ABL(1, 3)) return;           // ablation: staging only
 
-    for (int b = 0; b < NBLK; ++b) {
-        if (b == b_own) continue;
-        const uint32_t fp = fr[b * 64];
-        uint32_t rw[UB];
+    // Blocks of 16 regions in groups of P_GRP: all state words of a group are loaded first (one global
+    // latency per group, not per block), then the group's terms run from registers + LDS only.
+    for (int bg = 0; bg < NBLK; bg += P_GRP) {
+        uint32_t fpv[P_GRP], rwv[P_GRP][UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) rw[u] = rt[u][b * 64];
-        const uint32_t mbase = (uint32_t)b * (R_NB * REC);
-        if (Nreg - b * R_NB >= R_NB) {
-            // full block: one straight-line body of 16 * UB terms
+        for (int g = 0; g < P_GRP; ++g) {
+            const int b = (bg + g < NBLK) ? bg + g : NBLK - 1;
+            fpv[g] = fr[b * 64];
 #pragma unroll
-            for (int j = 0; j < R_NB; ++j) {
-                const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);   // f_c picks the k row
+            for (int u = 0; u < UB; ++u) rwv[g][u] = rt[u][b * 64];
+        }
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const uint32_t t = (rw[u] >> j) & 1u;                                           // r_m picks the column
-                    d[u] += *reinterpret_cast<const double *>(rb + kb + (t << 3) + (uint32_t)u * 48u);
+        for (int g = 0; g < P_GRP; ++g) {
+            const int b = bg + g;
+            if (b >= NBLK || b == b_own) continue;
+            if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g] + rwv[g][0] + rwv[g][UB - 1]); continue; }   // ablation: loads only
+            const uint32_t fp = fpv[g];
+            const uint32_t mbase = (uint32_t)b * (R_NB * REC);
+            if (Nreg - b * R_NB >= R_NB) {
+                // full block: one straight-line body of 16 * UB terms
+#pragma unroll
+                for (int j = 0; j < R_NB; ++j) {
+                    // f_c picks the k row (16 B each) of the record; bit 3 of the address is free for r_m
+                    const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        // r_m picks the column: (r word << 3 >> j) & 8 OR-ed in (one shift + one v_and_or)
+                        const uint32_t a = (((rwv[g][u] << 3) >> j) & 8u) | kb;
+                        d[u] += *reinterpret_cast<const double *>(rb + a + (uint32_t)u * 48u);
+                    }
                 }
-            }
-        } else {
-            const int mcount = Nreg - b * R_NB;
-            for (int j = 0; j < mcount; ++j) {
-                const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);
+            } else {
+                const int mcount = Nreg - b * R_NB;
+                for (int j = 0; j < mcount; ++j) {
+                    const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const uint32_t t = (rw[u] >> j) & 1u;
-                    d[u] += *reinterpret_cast<const double *>(rb + kb + (t << 3) + (uint32_t)u * 48u);
+                    for (int u = 0; u < UB; ++u) {
+                        const uint32_t t = (rwv[g][u] >> j) & 1u;
+                        d[u] += *reinterpret_cast<const double *>(rb + kb + (t << 3) + (uint32_t)u * 48u);
+                    }
                 }
             }
         }
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
         d[a] = on ? Pw[i * 64] : 0.0;
     }
     __syncthreads();     // tile staged
+    if (FCD_ABL(2, 3)) return;           // ablation: staging + loads + thresholds
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = q + 4 * a;
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
     }
     __syncthreads();
     if (q != 0) return;
+    if (FCD_ABL(2, 2)) return;           // ablation: no in-order part
 
     // the in-order part, one wave
     const double dpi = hyper[FCD_H_LNPI1] - hyper[FCD_H_LNPI0];
@@ -414,6 +432,7 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
                            g.GW, r_T);
         FCD_LAUNCH_CHECK();
     }
+    fcd_abl_refresh(s);
     int ub = 1;
     while (ub < 4 && (size_t)(ub * 2) * row_bytes <= 64 * 1024 && ub * 2 <= U) ub *= 2;
     if (const char *e = getenv("FCD_R_UB")) {   // tuning knob: patients per panel workgroup (1, 2, 4)

@@ -56,6 +56,7 @@ class GibbsEngine(object):
 
     def __init__(self, S_B, lM, Nreg, U, n_chains, chain0=0, seed=0, edge_index="symmetric", ctx=None,
                  region_major=True):
+        """region_major=False keeps only lM: the generic f / r kernels run (any shape, several times slower)."""
         import torch
         self.torch = torch
         self.ctx = ctx if ctx is not None else _lib.Context()
@@ -76,16 +77,19 @@ class GibbsEngine(object):
         self.cnt_r = torch.zeros((self.Nreg, self.U), dtype=torch.int32, device=dev)
         self.n_accumulated = 0
         self.ctx.call("fcd_ctx_reserve", self.Nreg, self.U, self.G)
-        self.lMd = None
+        self.lMd = self.lMf = None
         if region_major:
             self.lMd = torch.empty((self.U, self.Nreg, self.Nreg, 3, 2), dtype=torch.float64, device=dev)
+            self.lMf = torch.empty((self.C, self.U, 3, 2), dtype=torch.float64, device=dev)
             self.refresh_tables()
 
     def refresh_tables(self):
-        """Re-derive the region-major table after lM changed (a table build = a theta_sub change)."""
+        """Re-derive the two difference tables after lM changed (a table build = a theta_sub change)."""
         if self.lMd is not None:
             self.ctx.call("fcd_gibbs_region_tables", _lib.dptr(self.lM), self.Nreg, self.U, self.edge_mode,
                           _lib.dptr(self.lMd), _lib.stream_ptr())
+            self.ctx.call("fcd_gibbs_edge_tables", _lib.dptr(self.lM), self.Nreg, self.U, _lib.dptr(self.lMf),
+                          _lib.stream_ptr())
 
     # ---- hyper-parameters ----
     def set_hyper(self, gamma, pi2):
@@ -121,7 +125,7 @@ class GibbsEngine(object):
 
     # ---- moves ----
     def f_step(self, sweep):
-        self.ctx.call("fcd_gibbs_f_step", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.hyper),
+        self.ctx.call("fcd_gibbs_f_step", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMf), _lib.dptr(self.hyper),
                       _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
                       C.c_uint64(self.seed), int(sweep), _lib.stream_ptr())
 
@@ -131,7 +135,8 @@ class GibbsEngine(object):
                       int(sweep), self.edge_mode, _lib.stream_ptr())
 
     def sweeps(self, sweep0, n_sweeps, with_counts=False):
-        self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMd), _lib.dptr(self.hyper),
+        self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMf), _lib.dptr(self.lMd),
+                      _lib.dptr(self.hyper),
                       _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
                       C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode,
                       _lib.dptr(self.counts if with_counts else None), _lib.stream_ptr())

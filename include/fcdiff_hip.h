@@ -117,8 +117,13 @@ int fcd_gibbs_state_size(int64_t Nreg, int64_t U, int64_t G, size_t *f_bytes, si
 /* f ~ Uniform{0,1,2}, r ~ Bernoulli(pi) from the counter RNG (kinds 0, 1). */
 int fcd_gibbs_init(fcd_ctx *ctx, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                    int64_t chain0, uint64_t seed, double pi, fcd_stream stream);
-/* Redraw every f_c of every chain given r (edges are conditionally independent). */
-int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
+/* Edge-major DIFFERENCE table for the f step: lMf (C, U, 3, 2), lMf[c][u][l][k-1] = lM[c,u,k,l] - lM[c,u,0,l]
+ * (the log-odds of type k against type 0 contributed by patient u in mixture case l).  48*C*U bytes. */
+int fcd_gibbs_edge_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, double *lMf, fcd_stream stream);
+/* Redraw every f_c of every chain given r (edges are conditionally independent).  With lMf only the two
+ * log-odds against type 0 are accumulated (one 16-byte read + two adds per term); lMf == NULL runs the
+ * kernel that accumulates the three sums of fit.py:170-173 from lM directly. */
+int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                      uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                      int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream);
 /* Region-major DIFFERENCE table for the r step: lMd (U, Nreg, Nreg, 3, 2),
@@ -137,8 +142,8 @@ int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const do
                      int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream);
 /* n_sweeps x (f step, r step), sweeps numbered sweep0, sweep0+1, ...  When counts != NULL the pooled
  * statistics of the LAST sweep are stored there (see fcd_gibbs_stats). */
-int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMd, const double *hyper,
-                     uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
+                     const double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                      uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                      fcd_stream stream);
 /* Pooled sufficient statistics over the G chains (the all-reduce payload):

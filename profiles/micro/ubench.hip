@@ -1,0 +1,89 @@
+// Micro-benchmarks behind the kernel design choices (LDS gather patterns, fp64 add rate, clock).
+// hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench && ./ubench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d at %d\n", e, __LINE__); return 1; } } while (0)
+
+// MODE 0: ds_read_b64, each lane one of 6 addresses inside a 48-byte record (our gather pattern)
+// MODE 1: ds_read_b64, all 64 lanes distinct consecutive addresses
+// MODE 2: ds_read_b64, all lanes the same address
+// MODE 3: ds_read_b128, 3 distinct 16-byte addresses (f-step pattern)
+// MODE 4: no LDS: v_add_f64 only
+// MODE 5: ds_read_b64 pattern 0 without the add (read + xor into an int accumulator)
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long *cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) double lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 1e-3 * i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int s = sel[threadIdx.x & 63];     // 0..5
+    uint32_t a;
+    if (MODE == 0 || MODE == 5) a = s * 8;
+    else if (MODE == 1) a = lane * 8;
+    else if (MODE == 2) a = 0;
+    else a = (s % 3) * 16;
+    double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    const char *b = (const char *)lds;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t o = (uint32_t)((it & 7) * 6144 + j * 192);
+            if (MODE == 4) {
+                d0 += 1.0000001; d1 += 1.0000002; d2 += 1.0000003; d3 += 1.0000004;
+            } else if (MODE == 3) {
+                const double2 v0 = *(const double2 *)(b + a + o), v1 = *(const double2 *)(b + a + o + 48);
+                d0 += v0.x; d1 += v0.y; d2 += v1.x; d3 += v1.y;
+            } else {
+                d0 += *(const double *)(b + a + o);
+                d1 += *(const double *)(b + a + o + 48);
+                d2 += *(const double *)(b + a + o + 96);
+                d3 += *(const double *)(b + a + o + 144);
+            }
+        }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = d0 + d1 + d2 + d3;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+int run(const char *name, int waves_per_block, int *sel, double *out, long long *cyc) {
+    const int iters = 2000, blocks = 256;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, sel, out, cyc, 10);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, sel, out, cyc, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    long long c;
+    CHECK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    const double wave_instr = (double)iters * 16 * 4;      // read(+add) groups per wave
+    const double ns_per = ms * 1e6 / wave_instr;           // per wave-instruction-group, one wave's timeline
+    printf("%-44s waves/CU=%2d  %8.3f ms  %6.2f ns per (read+add) per wave  -> %6.2f ns per SIMD-slot; memtime ticks %lld (%.1f ticks/us)\n",
+           name, waves_per_block, ms, ns_per, ns_per / (waves_per_block / 4.0), c, c / (ms * 1e3));
+    return 0;
+}
+
+int main() {
+    int h[64];
+    for (int i = 0; i < 64; ++i) h[i] = (i * 7 + i / 5) % 6;
+    int *sel; double *out; long long *cyc;
+    CHECK(hipMalloc(&sel, 256)); CHECK(hipMalloc(&out, 256 * 1024 * 8)); CHECK(hipMalloc(&cyc, 256 * 8));
+    CHECK(hipMemcpy(sel, h, 256, hipMemcpyHostToDevice));
+    for (int wpb : {4, 16}) {
+        run<0>("b64 gather 6 addrs/48B (panel pattern)", wpb, sel, out, cyc);
+        run<1>("b64 64 distinct consecutive", wpb, sel, out, cyc);
+        run<2>("b64 all lanes same address", wpb, sel, out, cyc);
+        run<3>("b128 3 addrs (f pattern; 2 reads+4 adds/grp)", wpb, sel, out, cyc);
+        run<4>("v_add_f64 only (4 adds/grp)", wpb, sel, out, cyc);
+    }
+    return 0;
+}

@@ -303,7 +303,7 @@ def test_philox_device_equals_oracle(env):
                                                 (35, 6, 128, 9, "symmetric"), (16, 2, 64, 0, "reference")])
 def test_gibbs_chains_equal_oracle_state_for_state(env, N, U, G, chain0, mode, blocked):
     """init + 3 sweeps: every f_c and r_nu of every chain equals the C oracle's (same Philox counters).
-    blocked = the panel/diagonal r pass over the region-major table; otherwise the generic r kernel."""
+    blocked = difference tables (f: 2 log-odds per edge; r: panel + diagonal kernels); else the generic kernels."""
     (m, S_B, lM) = tables_for(env, N, 5, U, seed=N * 100 + U)
     seed = 0x0123456789ABCDEF + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=chain0, seed=seed, edge_index=mode, ctx=env.ctx,
