@@ -1,0 +1,116 @@
+"""
+The multi-process path on CPU: 2 ranks, gloo, 127.0.0.1.
+
+The product sampler loop (fcdiff_amd.gibbs.run_chains) only needs an object with sweeps/stats/mstep/accumulate;
+on a GPU that is the HIP engine.  Here an oracle-backed stand-in (C restatement, tests only) takes its place so
+that what runs under gloo is exactly the distributed logic: global chain ids per rank, the all-reduce of the
+pooled counts, the shared (pi, gamma) M-step.  Two ranks with 5 + 4 chains must reproduce one process with 9.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, theta_dict
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from fcdiff_amd.gibbs import mstep_from_counts, run_chains, shard_chains  # noqa: E402
+
+
+class OracleEngine(object):
+    """Same surface as fcdiff_amd.gibbs.GibbsEngine, computed by oracle/fcdiff_oracle.c (tests only)."""
+
+    def __init__(self, S_B, lM, Nreg, U, G, chain0, seed, gamma, pi, mode=1):
+        from oracle import c_oracle as CO
+        self.CO = CO
+        (self.S_B, self.lM, self.Nreg, self.U, self.G) = (S_B, lM, Nreg, U, G)
+        (self.chain0, self.seed, self.mode) = (chain0, seed, mode)
+        (self.gamma, self.pi) = (np.array(gamma, dtype=np.float64), float(pi))
+        (self.f, self.r) = CO.gibbs_init(G, Nreg, U, self.pi, seed, chain0)
+        self.cnt_r = np.zeros((Nreg, U), dtype=np.int64)
+        self.n_acc = 0
+
+    def sweeps(self, sweep0, n, with_counts=False):
+        lng, lnpi2 = np.log(self.gamma), np.log([1 - self.pi, self.pi])
+        for s in range(sweep0, sweep0 + n):
+            self.CO.gibbs_f_step(self.f, self.r, self.S_B, self.lM, lng, self.seed, s, self.chain0)
+            self.CO.gibbs_r_step(self.f, self.r, self.lM, lnpi2, self.seed, s, self.mode, self.chain0)
+
+    def stats(self):
+        return torch.from_numpy(self.CO.gibbs_stats(self.f, self.r).copy())
+
+    def mstep(self, counts):
+        (self.pi, self.gamma) = mstep_from_counts(counts.numpy(), self.Nreg, self.U)
+
+    def accumulate(self):
+        self.cnt_r += self.r.sum(axis=0, dtype=np.int64)
+        self.n_acc += 1
+
+
+def problem():
+    g = load_golden("G11_gibbs_conditionals_cfg1")
+    th = theta_dict(g["theta"])
+    (Nreg, U) = g["r_state"].shape
+    return g["lp_B_g_F"].sum(axis=1), g["lM"], Nreg, U, th
+
+
+def run_single(total, n_sweeps, seed):
+    (S_B, lM, Nreg, U, th) = problem()
+    eng = OracleEngine(S_B, lM, Nreg, U, total, 0, seed, th["gamma"], th["pi"])
+    run_chains(eng, n_sweeps, mstep_every=1, burn_in=1)
+    return eng
+
+
+def worker(rank, world, port, total, n_sweeps, seed, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (S_B, lM, Nreg, U, th) = problem()
+        (chain0, n_local) = shard_chains(total, world, rank)
+        eng = OracleEngine(S_B, lM, Nreg, U, n_local, chain0, seed, th["gamma"], th["pi"])
+        run_chains(eng, n_sweeps, mstep_every=1, burn_in=1)
+        cnt = torch.from_numpy(eng.cnt_r.copy())
+        dist.all_reduce(cnt)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=eng.f, r=eng.r, pi=eng.pi, gamma=eng.gamma,
+                 chain0=chain0, cnt_r=cnt.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_chains():
+    assert [shard_chains(10, 3, r) for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
+    assert [shard_chains(4096, 4, r) for r in range(4)] == [(0, 1024), (1024, 1024), (2048, 1024), (3072, 1024)]
+    tot = sum(shard_chains(8192, 8, r)[1] for r in range(8))
+    assert tot == 8192
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_process(tmp_path):
+    (total, n_sweeps, seed) = (9, 4, 77)
+    ref = run_single(total, n_sweeps, seed)
+    port = free_port()
+    mp.spawn(worker, args=(2, port, total, n_sweeps, seed, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
+    assert [int(p["chain0"]) for p in parts] == [0, 5]
+    np.testing.assert_array_equal(np.concatenate([p["f"] for p in parts]), ref.f)
+    np.testing.assert_array_equal(np.concatenate([p["r"] for p in parts]), ref.r)
+    for p in parts:
+        # every rank ends with the same pooled hyper-parameters, equal to the single-process ones
+        assert float(p["pi"]) == ref.pi
+        np.testing.assert_array_equal(p["gamma"], ref.gamma)
+        np.testing.assert_array_equal(p["cnt_r"], ref.cnt_r)
+    assert 0 < ref.pi < 1 and abs(ref.gamma.sum() - 1) < 1e-12
