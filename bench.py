@@ -113,10 +113,10 @@ def main():
             c.record()
             ev["f"].append((a, b_))
             ev["r"].append((b_, c))
-        if args.mstep_every and (s + 1) % args.mstep_every == 0:
-            counts = allreduce_counts(eng.stats())
-            eng.mstep(counts)
-        eng.accumulate()
+        do_m = bool(args.mstep_every and (s + 1) % args.mstep_every == 0)
+        counts = eng.tally(want_counts=do_m, accumulate=True)      # pooled counts + marginal counters, one pass
+        if do_m:
+            eng.mstep(allreduce_counts(counts))
 
     def fence():
         torch.cuda.synchronize()

@@ -60,11 +60,30 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->log_tab = nullptr;
     ctx->msg[0] = 0;
     int rc = fcd_ws_reserve(ctx, 1u << 20);
     if (rc) {
         delete ctx;
         return rc;
+    }
+    {
+        // table of K_lik's log: cell i = top 6 mantissa bits of the [1,2)-normalised argument; cells 32..63 are
+        // halved into [0.75, 1); the two cells around 1 use m_i = 1 (no cancellation near 1)
+        double tab[128];
+        for (int i = 0; i < 64; ++i) {
+            double m = 1.0 + (i + 0.5) / 64.0;
+            if (i >= 32) m *= 0.5;
+            if (i == 0 || i == 63) m = 1.0;
+            tab[i] = 1.0 / m;
+            tab[64 + i] = -log(tab[i]);      // log of the ROUNDED reciprocal's inverse: the identity stays exact
+        }
+        hipError_t e = hipMalloc(&ctx->log_tab, sizeof(tab));
+        if (e == hipSuccess) e = hipMemcpy(ctx->log_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fcd_ctx_destroy(ctx);
+            return (int)e;
+        }
     }
     *out = ctx;
     return FCD_OK;
@@ -74,6 +93,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (!ctx) return FCD_OK;
     hipError_t e = hipSuccess;
     if (ctx->ws) e = hipFree(ctx->ws);
+    if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     delete ctx;
     return (int)e;
 }
@@ -85,7 +105,7 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
     const size_t en = (size_t)ctx->num_cu * 8 * 8 * sizeof(double);  // energy partials
     if (en > need) need = en;
     const int64_t NBLK = (Nreg + 15) / 16;
-    const size_t panel = (size_t)GW * U * 16 * 64 * sizeof(double)         // r step: per-block partial sums,
+    const size_t panel = 3 * (size_t)GW * U * 16 * 64 * sizeof(double)     // r step: per-block partial sums + 2 threshold buffers,
                          + (size_t)GW * Nreg * NBLK * 64 * 4                // packed f,
                          + (size_t)GW * U * NBLK * 64 * 2 + 512;            // per-lane r words
     if (panel > need) need = panel;

@@ -12,6 +12,7 @@ struct fcd_ctx {
     int num_cu;
     void *ws;          // reduction / partial-sum workspace
     size_t ws_bytes;
+    void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
     char msg[256];
 };
 

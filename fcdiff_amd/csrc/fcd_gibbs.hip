@@ -224,6 +224,140 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f step, pair form (U <= 64).  The kernel is bound by wave-wide LDS reads (one per gathered value whatever
+// the number of distinct addresses: profiles/r01_ubench_lds_fp64.txt), so the tile holds records for PAIRS of
+// patients (u, u+1): for each of the 16 values of (x_u, x_u+1, a_u, a_u+1), x = r_n xor r_m, a = r_n and r_m,
+//   rec[slot] = lMf[c][u][l(x_u, a_u)][:] + lMf[c][u+1][l(x_u+1, a_u+1)][:]        (2 doubles, 256 B per pair)
+// built in LDS while staging.  One ds_read_b128 + two fp64 adds then cover two patients.  r comes as per-lane
+// words over patients (r_U, made by pack_ru_kernel): no scalar loads inside the loop.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW32, int GW,
+                                                      uint32_t *__restrict__ r_U) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);      // (w, n, word)
+    if (item >= GW * Nreg * NW32) return;
+    const int jw = item % NW32, wn = item / NW32;               // wn = w*Nreg + n
+    uint32_t v = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const int u = jw * 32 + j;
+        if (u < U) v |= (uint32_t)((r_bits[(int64_t)wn * U + u] >> lane) & 1ull) << j;
+    }
+    r_U[(int64_t)item * 64 + lane] = v;
+}
+
+constexpr int FP_EC = 8;     // edges per tile
+template <int NW32>
+__global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
+                                                            const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
+                                                            const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
+                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
+    const int NPAIR = (U + 1) >> 1;
+    const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
+    const int ne = (int)((C - c0 < FP_EC) ? (C - c0) : FP_EC);
+    double2 *single = reinterpret_cast<double2 *>(tile) + (size_t)FP_EC * NPAIR * 16;
+    {
+        // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
+        const int n_d2 = ne * U * 3;
+        const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        for (int i = threadIdx.x; i < n_d2; i += blockDim.x) single[i] = src[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging
+    uint32_t X[FP_EC][NW32], A[FP_EC][NW32];
+    if (w < GW) {
+        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW32 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < FP_EC; ++e) {
+            int n, m;
+            fcd_edge_to_pair(c0 + (e < ne ? e : 0), n, m);
+#pragma unroll
+            for (int j = 0; j < NW32; ++j) {
+                const uint32_t rn = ru[(int64_t)(n * NW32 + j) * 64], rm = ru[(int64_t)(m * NW32 + j) * 64];
+                X[e][j] = rn ^ rm;
+                A[e][j] = rn & rm;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // pair records from the single rows in LDS: a thread keeps its slot (blockDim is a multiple of 16)
+        double2 *dst = reinterpret_cast<double2 *>(tile);
+        const int slot = threadIdx.x & 15;
+        const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
+        const bool valid = !((x0 & a0) | (x1 & a1));
+        const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
+        const int total = ne * NPAIR;
+        for (int ep = threadIdx.x >> 4; ep < total; ep += blockDim.x >> 4) {
+            const int e = ep / NPAIR, pr = ep - e * NPAIR;
+            const int u = 2 * pr;
+            double2 v = make_double2(0.0, 0.0);
+            if (valid) {
+                const double2 *su = single + (e * U + u) * 3;
+                v = su[l0];
+                if (u + 1 < U) {
+                    const double2 v1 = su[3 + l1];
+                    v.x += v1.x;
+                    v.y += v1.y;
+                }
+            }
+            dst[ep * 16 + slot] = v;
+        }
+    }
+    __syncthreads();
+    if (w >= GW) return;
+    if (FCD_ABL(0, 3)) return;           // ablation: staging only
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
+    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    fcd_u4 rnd = {0, 0, 0, 0};
+    const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = half a 32-bit word
+
+#pragma unroll
+    for (int e = 0; e < FP_EC; ++e) {
+        if (e < ne) {
+            const int64_t c = c0 + e;
+            const char *tb = reinterpret_cast<const char *>(tile) + (int64_t)e * NPAIR * 256;
+            double b1 = 0.0, b2 = 0.0;
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t xs = (g & 1) ? (X[e][(g >> 1) < NW32 ? (g >> 1) : 0] >> 16) : X[e][(g >> 1) < NW32 ? (g >> 1) : 0];
+                const uint32_t as = (g & 1) ? (A[e][(g >> 1) < NW32 ? (g >> 1) : 0] >> 16) : A[e][(g >> 1) < NW32 ? (g >> 1) : 0];
+                const char *gb = tb + g * (8 * 256);
+                if (NPAIR - 8 * g >= 8) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        // slot = (x_u, x_u+1, a_u, a_u+1) -> 16-byte records
+                        const uint32_t off = (((xs >> (2 * p)) & 3u) << 4) | (((as >> (2 * p)) & 3u) << 6);
+                        const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                        b1 += v.x;
+                        b2 += v.y;
+                    }
+                } else {
+                    for (int p = 0; p < NPAIR - 8 * g; ++p) {
+                        const uint32_t off = (((xs >> (2 * p)) & 3u) << 4) | (((as >> (2 * p)) & 3u) << 6);
+                        const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                        b1 += v.x;
+                        b2 += v.y;
+                    }
+                }
+            }
+            b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
+            b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+            if (FCD_ABL(0, 2)) {             // ablation: no RNG / exp
+                f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
+                continue;
+            }
+            if ((e & 1) == 0) rnd = fcd_philox((uint32_t)(c >> 1), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is even
+            const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(0.0, b1, b2, x);
+        }
+    }
+}
+
 // conditional log-weights of every r site given the CURRENT state (nothing updated): parity hook.
 __global__ __launch_bounds__(64) void gibbs_cond_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
                                                           const uint8_t *__restrict__ f_state,
@@ -330,6 +464,78 @@ __global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restr
         uint32_t s = 0;
         for (int w = 0; w < GW; ++w) s += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
         cnt_r[i] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tally: pooled counts AND marginal counters in one pass over the state (f_state is read once, 16 bytes
+// per lane: a wave covers the 16 chain words x 64 chains of an edge with a single load instruction).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gibbs_tally_kernel(const uint8_t *__restrict__ f_state,
+                                                           const uint64_t *__restrict__ r_bits, int64_t C, int64_t NU, int GW,
+                                                           int64_t G, unsigned long long *__restrict__ counts,
+                                                           uint32_t *__restrict__ cnt_f, uint32_t *__restrict__ cnt_r) {
+    __shared__ unsigned long long red[16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 3, wrow = lane >> 2;          // 16-byte piece of the 64-byte row, chain word within a group of 16
+    unsigned long long tot1 = 0, tot2 = 0, n_edges = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 16 + wave; c < C; c += (int64_t)gridDim.x * 16) {
+        uint32_t ones = 0, twos = 0;
+        for (int wg = 0; wg < GW; wg += 16) {
+            const int w = wg + wrow;
+            if (w < GW) {
+                uint4 v = *reinterpret_cast<const uint4 *>(f_state + ((int64_t)w * C + c) * 64 + sub * 16);
+                const uint32_t act = (uint32_t)(fcd_active_mask(w, G) >> (sub * 16)) & 0xFFFFu;
+                if (act != 0xFFFFu) {   // last, partial chain word: drop the bytes of chains that do not exist
+                    v.x &= (((act & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.y &= ((((act >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.z &= ((((act >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.w &= ((((act >> 12) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                }
+                ones += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+                        __popc(v.w & 0x01010101u);
+                twos += __popc((v.x >> 1) & 0x01010101u) + __popc((v.y >> 1) & 0x01010101u) +
+                        __popc((v.z >> 1) & 0x01010101u) + __popc((v.w >> 1) & 0x01010101u);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            ones += __shfl_xor(ones, o, 64);
+            twos += __shfl_xor(twos, o, 64);
+        }
+        if (lane == 0) {
+            if (cnt_f) {
+                cnt_f[c * 3 + 0] += (uint32_t)G - ones - twos;
+                cnt_f[c * 3 + 1] += ones;
+                cnt_f[c * 3 + 2] += twos;
+            }
+            tot1 += ones;
+            tot2 += twos;
+            n_edges += 1;
+        }
+    }
+    unsigned long long cr = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NU; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t sr = 0;
+        for (int w = 0; w < GW; ++w) sr += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
+        if (cnt_r) cnt_r[i] += sr;
+        cr += sr;
+    }
+    if (counts) {
+        // one set of atomics per BLOCK (same-address atomics serialise): wave sums -> LDS -> thread 0..3
+        for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+        if (lane == 0) {
+            red[wave][0] = cr;
+            red[wave][1] = n_edges * (unsigned long long)G - tot1 - tot2;
+            red[wave][2] = tot1;
+            red[wave][3] = tot2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            unsigned long long t = 0;
+            for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+            if (t) atomicAdd(&counts[threadIdx.x], t);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 4) counts[4] = (unsigned long long)G;
     }
 }
 
@@ -506,6 +712,37 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
                                (hipStream_t)stream);
     fcd_abl_refresh((hipStream_t)stream);
     const int wpb = g.GW < 16 ? g.GW : 16;
+    hipStream_t s = (hipStream_t)stream;
+    const int NW32 = (int)((U + 31) / 32);
+    const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
+    if (NW32 <= 2 && pair_shmem <= 96 * 1024 && (int64_t)g.GW * Nreg * NW32 < INT32_MAX / 4) {
+        // pair form: per-lane r words over patients (scratch in the ctx workspace), pair records in LDS
+        const size_t ru_bytes = (size_t)g.GW * Nreg * NW32 * 64 * sizeof(uint32_t);
+        rc = fcd_ws_reserve(ctx, ru_bytes);
+        if (rc) return rc;
+        uint32_t *r_U = (uint32_t *)ctx->ws;
+        const int64_t items = (int64_t)g.GW * Nreg * NW32;
+        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NW32,
+                           g.GW, r_U);
+        FCD_LAUNCH_CHECK();
+        dim3 grid((unsigned)((g.C + FP_EC - 1) / FP_EC), (unsigned)((g.GW + wpb - 1) / wpb));
+        if (pair_shmem > 64 * 1024) {
+            hipError_t err = NW32 == 1 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_pair_kernel<1>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem)
+                                       : hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_pair_kernel<2>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem);
+            if (err != hipSuccess) return (int)err;
+        }
+        if (NW32 == 1)
+            hipLaunchKernelGGL(gibbs_f_pair_kernel<1>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
+                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
+        else
+            hipLaunchKernelGGL(gibbs_f_pair_kernel<2>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
+                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
+        FCD_LAUNCH_CHECK();
+        return FCD_OK;
+    }
+    // U > 64: log-odds form with scalar r masks
     const size_t per_edge = (size_t)U * 48;
     int64_t e = (int64_t)(24 * 1024 / per_edge);
     if (e < 1) e = 1;
@@ -518,7 +755,7 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
         if (err != hipSuccess) return (int)err;
     }
     dim3 grid((unsigned)((g.C + e - 1) / e), (unsigned)((g.GW + wpb - 1) / wpb));
-    hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), shmem, (hipStream_t)stream, S_B, lMf, hyper, f_state, r_bits,
+    hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), shmem, s, S_B, lMf, hyper, f_state, r_bits,
                        (int)Nreg, (int)U, g.C, g.GW, (int)e, (uint32_t)chain0, seed, (uint32_t)sweep);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
@@ -579,6 +816,25 @@ extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const 
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(gibbs_accum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f_state, r_bits, g.C,
                        Nreg * U, g.GW, G, cnt_f, cnt_r);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                               int64_t G, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream) {
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: null pointer");
+    if ((cnt_f == nullptr) != (cnt_r == nullptr)) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: cnt_f and cnt_r go together");
+    if (!counts && !cnt_f) return FCD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (counts) FCD_HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), s));
+    int64_t blocks = (g.C + 15) / 16;
+    const int64_t cap = (int64_t)ctx->num_cu * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, f_state, r_bits, g.C, Nreg * U, g.GW, G,
+                       reinterpret_cast<unsigned long long *>(counts), cnt_f, cnt_r);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

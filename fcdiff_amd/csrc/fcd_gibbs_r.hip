@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
 
 // ---------------------------------------------------------------------------------------------
 // per-pass packing of the chain state into the two forms the blocked kernels read with one coalesced
-// load per 16 regions:
-//   f_r[w][n][b][lane]  uint32: 2 bits per region m = 16 b + j: f of edge(n, m) of chain 64 w + lane
-//   r_T[w][u][b][lane]  uint16: bit j = r_{16 b + j, u} of chain 64 w + lane
+// load per 16 regions (= 8 PAIRS of regions (2p, 2p+1)):
+//   f_r[w][n][b][lane]  uint32: 4 bits per pair p of block b: q = 3 f(n, m) + f(n, m+1), m = 16 b + 2 p
+//   r_T[w][u][b][lane]  uint16: bit j = r_{16 b + j, u} of chain 64 w + lane (2 bits per pair)
+// (f of a region beyond Nreg or of m == n counts as 0; those table records are zero.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int GW,
                                                      int C32, int mode, uint32_t *__restrict__ f_r) {
@@ -67,9 +68,12 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
     const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64 + lane;
     uint32_t v = 0;
 #pragma unroll
-    for (int j = 0; j < R_NB; ++j) {
-        const int m = b * R_NB + j;
-        if (m < Nreg && m != n) v |= (uint32_t)fw[(int64_t)fcd_pair_to_edge(n, m, mode) * 64] << (2 * j);
+    for (int p = 0; p < R_NB / 2; ++p) {
+        const int m0 = b * R_NB + 2 * p, m1 = m0 + 1;
+        uint32_t k0 = 0, k1 = 0;
+        if (m0 < Nreg && m0 != n) k0 = fw[(int64_t)fcd_pair_to_edge(n, m0, mode) * 64];
+        if (m1 < Nreg && m1 != n) k1 = fw[(int64_t)fcd_pair_to_edge(n, m1, mode) * 64];
+        v |= (k0 * 3u + k1) << (4 * p);
     }
     f_r[(int64_t)item * 64 + lane] = v;
 }
@@ -91,10 +95,15 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
 
 // ---------------------------------------------------------------------------------------------
 // panel kernel.  grid = (regions of the block, patient chunks of UB, groups of chain words);
-// block = 64 * (chain words per group).  LDS tile [m][u][k][t] (UB*48 bytes per region m) built from the
-// UB rows lMd[u][n][:]; the patient offset is then an instruction immediate.
-// For every other block of 16 regions a lane loads one uint32 of f and UB uint16 of r; a term is two integer
-// VALU ops (bit extract, shift-add), one 8-byte LDS read and one fp64 add.
+// block = 64 * (chain words per group).
+//
+// What limits this kernel is the number of wave-wide LDS reads (one per gathered value whatever the
+// number of distinct addresses: profiles/r01_ubench_lds_fp64.txt), so the tile holds PAIR records: for the
+// pair of regions (m, m+1) and patient u, all 9 x 4 sums
+//   pr[q = 3k + k'][tt = t + 2t'] = lMd[u][n][m][k][t] + lMd[u][n][m+1][k'][t']              (288 bytes)
+// built in LDS from the two single rows while staging.  One 8-byte LDS read and one fp64 add then cover
+// TWO regions; the address is  q*32 + tt*8  from the packed f / r words (2 integer ops per term + 2 per pair).
+// LDS: singles [UB][Nreg*6] doubles (scratch) + pairs [8*NBLK][UB][36] doubles.
 // P[((w*U + u)*R_NB + i)][lane], i = n - 16 b_own.
 // ---------------------------------------------------------------------------------------------
 constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
@@ -102,51 +111,79 @@ template <int UB>
 __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__ lMd, const uint32_t *__restrict__ f_r,
                                                       const uint16_t *__restrict__ r_T, double *__restrict__ P, int Nreg,
                                                       int U, int NBLK, int GW, int b_own, int nb) {
-    extern __shared__ double rows[];   // [Nreg][UB][6]
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n_pairs = NBLK * (R_NB / 2);
+    double *pairs = smem;                                  // [n_pairs][UB][36]
+    double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][Nreg*6]
     const int n = b_own * R_NB + blockIdx.x;
     const int u0 = blockIdx.y * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
     {
-        // source rows are contiguous 16-byte (k) pairs: copy as double2, interleaving the patients.
-        // One flat loop over (patient, element): every thread's loads are independent.
         const int row_d2 = Nreg * 3;
-        double2 *dst = reinterpret_cast<double2 *>(rows);
+        double2 *dst = reinterpret_cast<double2 *>(single);
         for (int it = threadIdx.x; it < UB * row_d2; it += blockDim.x) {
             const int u = it / row_d2, i = it - u * row_d2;
-            const int us = u < nu ? u : nu - 1;       // tail chunk: replicate the last patient (never stored)
-            const double2 *src = reinterpret_cast<const double2 *>(lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6);
-            const int m = i / 3, k = i - m * 3;
-            dst[(m * UB + u) * 3 + k] = src[i];
+            const int us = u < nu ? u : nu - 1;            // tail chunk: replicate the last patient (never stored)
+            dst[it] = reinterpret_cast<const double2 *>(lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i];
         }
     }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (w >= GW) return;
-    const uint32_t *__restrict__ fr = f_r + ((int64_t)w * Nreg + n) * NBLK * 64 + lane;
+    const bool live = w < GW;
+    const uint32_t *__restrict__ fr = f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64 + lane;
     const uint16_t *__restrict__ rt[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         const int uu = u < nu ? u : nu - 1;
-        rt[u] = r_T + ((int64_t)w * U + u0 + uu) * NBLK * 64 + lane;
+        rt[u] = r_T + ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64 + lane;
     }
-    const char *rb = reinterpret_cast<const char *>(rows);
+    // state words of the first group of blocks: issued before the barriers, their latency hides behind the staging
+    uint32_t fpv[P_GRP], rwv[P_GRP][UB];
+#pragma unroll
+    for (int g = 0; g < P_GRP; ++g) {
+        const int b = (g < NBLK) ? g : NBLK - 1;
+        fpv[g] = fr[b * 64];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) rwv[g][u] = (uint32_t)rt[u][b * 64] << 3;   // tt*8 sits at bits 3..4 after >> 2p
+    }
+    __syncthreads();
+    {
+        // pair records: each thread keeps one of the 36 (q, tt) entries and walks the (pair, patient) list
+        const int e = threadIdx.x % 36, step = blockDim.x / 36;
+        const int q = e >> 2, tt = e & 3;
+        const int k = q / 3, k2 = q - 3 * k;
+        const int o0 = k * 2 + (tt & 1), o1 = k2 * 2 + (tt >> 1);
+        if ((int)threadIdx.x < step * 36) {
+            for (int pu = threadIdx.x / 36; pu < n_pairs * UB; pu += step) {
+                const int u = pu % UB, m = 2 * (pu / UB);
+                const double *su = single + u * Nreg * 6 + m * 6;
+                double v = 0.0;
+                if (m < Nreg) v = su[o0];
+                if (m + 1 < Nreg) v += su[6 + o1];
+                pairs[pu * 36 + e] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const char *pb = reinterpret_cast<const char *>(pairs);
     double d[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
-    constexpr uint32_t REC = UB * 48u;   // bytes per region m in the tile
-    if (FCD_ABL(1, 3)) return;           // ablation: staging only
+    constexpr uint32_t REC = UB * 288u;   // bytes per pair of regions in the tile
+    if (FCD_ABL(1, 3)) return;            // ablation: staging only
 
-    // Blocks of 16 regions in groups of P_GRP: all state words of a group are loaded first (one global
-    // latency per group, not per block), then the group's terms run from registers + LDS only.
+    // Blocks of 16 regions in groups of P_GRP: the state words of the NEXT group are requested before the
+    // current group's terms run, so no global latency sits on the loop.
     for (int bg = 0; bg < NBLK; bg += P_GRP) {
-        uint32_t fpv[P_GRP], rwv[P_GRP][UB];
+        uint32_t fpn[P_GRP], rwn[P_GRP][UB];
+        const bool more = bg + P_GRP < NBLK;
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
-            const int b = (bg + g < NBLK) ? bg + g : NBLK - 1;
-            fpv[g] = fr[b * 64];
+            const int b = (bg + P_GRP + g < NBLK) ? bg + P_GRP + g : NBLK - 1;
+            fpn[g] = more ? fr[b * 64] : 0u;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) rwv[g][u] = rt[u][b * 64];
+            for (int u = 0; u < UB; ++u) rwn[g][u] = more ? (uint32_t)rt[u][b * 64] << 3 : 0u;
         }
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
@@ -154,31 +191,23 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
             if (b >= NBLK || b == b_own) continue;
             if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g] + rwv[g][0] + rwv[g][UB - 1]); continue; }   // ablation: loads only
             const uint32_t fp = fpv[g];
-            const uint32_t mbase = (uint32_t)b * (R_NB * REC);
-            if (Nreg - b * R_NB >= R_NB) {
-                // full block: one straight-line body of 16 * UB terms
+            const uint32_t base = (uint32_t)b * ((R_NB / 2) * REC);
 #pragma unroll
-                for (int j = 0; j < R_NB; ++j) {
-                    // f_c picks the k row (16 B each) of the record; bit 3 of the address is free for r_m
-                    const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);
+            for (int p = 0; p < R_NB / 2; ++p) {
+                // q picks the 32-byte (k, k') row of the pair record; bits 3..4 of the address are free for (t, t')
+                const uint32_t qb = (((fp >> (4 * p)) & 15u) << 5) + (base + (uint32_t)p * REC);
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        // r_m picks the column: (r word << 3 >> j) & 8 OR-ed in (one shift + one v_and_or)
-                        const uint32_t a = (((rwv[g][u] << 3) >> j) & 8u) | kb;
-                        d[u] += *reinterpret_cast<const double *>(rb + a + (uint32_t)u * 48u);
-                    }
-                }
-            } else {
-                const int mcount = Nreg - b * R_NB;
-                for (int j = 0; j < mcount; ++j) {
-                    const uint32_t kb = (((fp >> (2 * j)) & 3u) << 4) + (mbase + (uint32_t)j * REC);
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const uint32_t t = (rwv[g][u] >> j) & 1u;
-                        d[u] += *reinterpret_cast<const double *>(rb + kb + (t << 3) + (uint32_t)u * 48u);
-                    }
+                for (int u = 0; u < UB; ++u) {
+                    const uint32_t a = ((rwv[g][u] >> (2 * p)) & 24u) | qb;
+                    d[u] += *reinterpret_cast<const double *>(pb + a + (uint32_t)u * 288u);
                 }
             }
+        }
+#pragma unroll
+        for (int g = 0; g < P_GRP; ++g) {
+            fpv[g] = fpn[g];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) rwv[g][u] = rwn[g][u];
         }
     }
     const int i = n - b_own * R_NB;
@@ -188,21 +217,50 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// thresholds logit(x) of the counter RNG for one block of 16 regions: thr[((w*U + u)*R_NB + i)][lane].
+// r_nu = 1  <=>  thr < ln(pi/(1-pi)) + d.  They depend on (seed, chain, sweep, site) only, so they are made
+// ahead of the in-order part: by this kernel for block 0, by the idle waves of gibbs_r_diag for the others.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
+                                uint32_t k0, uint32_t k1, int lane) {
+    const int n = B0 + 2 * p;                    // B0 is even: both halves of a counter block belong to this tile
+    const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
+    thr_wu[(2 * p) * 64 + lane] = fcd_logit(fcd_u53(x.x, x.y));
+    thr_wu[(2 * p + 1) * 64 + lane] = fcd_logit(fcd_u53(x.z, x.w));
+}
+
+__global__ __launch_bounds__(256) void r_thr0_kernel(double *__restrict__ thr, int U, uint32_t chain0, uint64_t seed,
+                                                     uint32_t sweep) {
+    const int u = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double *thr_wu = thr + (((int64_t)w * U + u) * R_NB) * 64;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    thr_pair(thr_wu, 0, 2 * q, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
+    thr_pair(thr_wu, 0, 2 * q + 1, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
+}
+
+// f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
+__device__ inline uint32_t f_of(uint32_t word, int j) {
+    const uint32_t q = (word >> (4 * (j >> 1))) & 15u;
+    const uint32_t hi = (q * 11u) >> 5;          // q / 3 for q in 0..8
+    return (j & 1) ? q - 3u * hi : hi;
+}
+
+// ---------------------------------------------------------------------------------------------
 // diagonal kernel.  grid = (U, GW); block = 4 waves = ONE (patient, chain word).
-// Everything that does not depend on the in-order dependence is spread over the four waves first:
-//   wave q: thresholds logit(x_i) of the counter RNG for i = 4q .. 4q+3, and for rows i = q, q+4, ...
-//           the panel sum plus the terms against OLD r_j of later regions j > i of the block.
-// After one barrier wave 0 walks the 16 regions in order: compare -> for j > i: d_j += term(j, i; r_i);
-// no exp / division / RNG on that dependent chain.
+// Phase A, all four waves: stage the diagonal tile lMd[u][B0+i][B0+j]; wave q takes rows i = q, q+4, ..:
+//   panel sum + the terms against the OLD r_j of later regions j > i of the block.
+// Phase B: wave 0 walks the 16 regions in order: compare -> for j > i: d_j += term(j, i; r_i) -- all LDS reads
+//   of a step are issued before the first add, and there is no exp / division / RNG on the chain;
+//   meanwhile waves 1..3 compute the NEXT block's thresholds (Philox + logit) for the next launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int D_WAVES = 4;
 __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__restrict__ lMd, const double *__restrict__ hyper,
                                                              const uint32_t *__restrict__ f_r, uint16_t *__restrict__ r_T,
                                                              uint64_t *__restrict__ r_bits, const double *__restrict__ P,
+                                                             const double *__restrict__ thr_cur, double *__restrict__ thr_next,
                                                              int Nreg, int U, int NBLK, int b_own, int nb,
                                                              uint32_t chain0, uint64_t seed, uint32_t sweep) {
     __shared__ double tile[R_NB * R_NB * 6];   // [i][j][k][t]
-    __shared__ double sh_thr[R_NB][64];
     __shared__ double sh_d[R_NB][64];
     __shared__ uint32_t sh_fp[R_NB][64];
     const int u = blockIdx.x, w = blockIdx.y;
@@ -213,24 +271,14 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
         const int j6 = t % (nb * 6), i = t / (nb * 6);
         tile[i * R_NB * 6 + j6] = lMd[(((int64_t)u * Nreg + B0 + i) * Nreg + B0) * 6 + j6];
     }
-    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint16_t *__restrict__ rTw = r_T + (((int64_t)w * U + u) * NBLK + b_own) * 64 + lane;
+    const int64_t wu = (int64_t)w * U + u;
+    uint16_t *__restrict__ rTw = r_T + (wu * NBLK + b_own) * 64 + lane;
     const uint32_t old = *rTw;
-    const double *__restrict__ Pw = P + (((int64_t)w * U + u) * R_NB) * 64 + lane;
+    const double *__restrict__ Pw = P + (wu * R_NB) * 64 + lane;
     const uint32_t *__restrict__ frw = f_r + (((int64_t)w * Nreg + B0) * NBLK + b_own) * 64 + lane;
     const char *tb = reinterpret_cast<const char *>(tile);
 
-    // thresholds of regions 4q .. 4q+3 (B0 and 4q are even: both halves of a counter block are used)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int i = 4 * q + 2 * p;
-        const int n = B0 + i;
-        const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
-        sh_thr[i][lane] = fcd_logit(fcd_u53(x.x, x.y));
-        sh_thr[i + 1][lane] = fcd_logit(fcd_u53(x.z, x.w));
-    }
-    // rows i = q, q+4, q+8, q+12: f words, panel sums
+    // rows i = q, q+4, q+8, q+12: f words, panel sums; the chain wave also requests its thresholds now
     uint32_t fp[4];
     double d[4];
 #pragma unroll
@@ -240,32 +288,53 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
         fp[a] = on ? frw[(int64_t)i * NBLK * 64] : 0u;
         d[a] = on ? Pw[i * 64] : 0.0;
     }
+    double thr[R_NB];
+    if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < R_NB; ++i) thr[i] = thr_cur[(wu * R_NB + i) * 64 + lane];
+    }
     __syncthreads();     // tile staged
-    if (FCD_ABL(2, 3)) return;           // ablation: staging + loads + thresholds
+    if (FCD_ABL(2, 3)) return;           // ablation: staging + loads
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = q + 4 * a;
-        // terms against regions of the block that come later in the scan: their OLD value
-        for (int j = i + 1; j < nb; ++j) {
+        // terms against regions of the block that come later in the scan: their OLD value.
+        // All reads first, then the adds: one LDS latency per row instead of one per term.
+        double tmp[R_NB];
+#pragma unroll
+        for (int j = 1; j < R_NB; ++j) {
+            const bool on = j > i && j < nb;
             const uint32_t t = (old >> j) & 1u;
-            d[a] += *reinterpret_cast<const double *>(tb + (((fp[a] >> (2 * j)) & 3u) << 4) + (t << 3) +
-                                                      (uint32_t)((i * R_NB + j) * 48));
+            tmp[j] = on ? *reinterpret_cast<const double *>(tb + (f_of(fp[a], j) << 4) + (t << 3) +
+                                                            (uint32_t)((i * R_NB + j) * 48))
+                        : 0.0;
         }
+#pragma unroll
+        for (int j = 1; j < R_NB; ++j) d[a] += tmp[j];
         sh_d[i][lane] = d[a];
         sh_fp[i][lane] = fp[a];
     }
     __syncthreads();
-    if (q != 0) return;
+    if (q != 0) {
+        // next block's thresholds on the otherwise idle waves: pairs 0-2, 3-5, 6-7
+        if (b_own + 1 < NBLK) {
+            double *thr_wu = thr_next + (wu * R_NB) * 64;
+            const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+            const int p0 = (q - 1) * 3, p1 = (q == 3) ? 8 : p0 + 3;
+            for (int p = p0; p < p1; ++p)
+                thr_pair(thr_wu, B0 + R_NB, p, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
+        }
+        return;
+    }
     if (FCD_ABL(2, 2)) return;           // ablation: no in-order part
 
     // the in-order part, one wave
     const double dpi = hyper[FCD_H_LNPI1] - hyper[FCD_H_LNPI0];
-    double dd[R_NB], thr[R_NB];
+    double dd[R_NB];
     uint32_t ff[R_NB];
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         dd[i] = sh_d[i][lane];
-        thr[i] = sh_thr[i][lane];
         ff[i] = sh_fp[i][lane];
     }
     uint32_t fresh = 0;
@@ -274,12 +343,14 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
         if (i < nb) {
             const uint32_t t = thr[i] < (dpi + dd[i]) ? 1u : 0u;
             fresh |= t << i;
+            double tmp[R_NB];
 #pragma unroll
-            for (int j = i + 1; j < R_NB; ++j) {
-                if (j < nb)
-                    dd[j] += *reinterpret_cast<const double *>(tb + (((ff[j] >> (2 * i)) & 3u) << 4) + (t << 3) +
-                                                               (uint32_t)((j * R_NB + i) * 48));
-            }
+            for (int j = i + 1; j < R_NB; ++j)
+                tmp[j] = (j < nb) ? *reinterpret_cast<const double *>(tb + (f_of(ff[j], i) << 4) + (t << 3) +
+                                                                      (uint32_t)((j * R_NB + i) * 48))
+                                  : 0.0;
+#pragma unroll
+            for (int j = i + 1; j < R_NB; ++j) dd[j] += tmp[j];
         }
     }
     *rTw = (uint16_t)fresh;
@@ -355,7 +426,7 @@ template <int UB>
 int launch_panel(const double *lMd, const uint32_t *f_r, const uint16_t *r_T, double *P, int64_t Nreg, int64_t U, int NBLK,
                  const fcd_geo &g, int b_own, int nb, hipStream_t s) {
     const int wpb = g.GW < 16 ? g.GW : 16;
-    const size_t shmem = (size_t)UB * Nreg * 48;
+    const size_t shmem = ((size_t)NBLK * (R_NB / 2) * UB * 36 + (size_t)UB * Nreg * 6) * sizeof(double);
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_r_panel<UB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -400,8 +471,8 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
         return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
     hipStream_t s = (hipStream_t)stream;
-    const size_t row_bytes = (size_t)Nreg * 48;
-    if (!lMd || row_bytes > 160 * 1024 || U > 65535) {
+    const size_t per_u_need = ((size_t)((Nreg + R_NB - 1) / R_NB) * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
+    if (!lMd || per_u_need > 156 * 1024 || U > 65535) {
         // generic path: direct gathers from the edge-major table
         const size_t shmem = (size_t)Nreg * 8 + (size_t)R_WAVES * 2 * 64 * 8;
         if (shmem > 64 * 1024) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld exceeds the LDS mask array", Nreg);
@@ -418,11 +489,12 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     const size_t r_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t);
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, p_bytes + f_bytes + r_bytes + 512);
+    rc = fcd_ws_reserve(ctx, 3 * p_bytes + f_bytes + r_bytes + 512);
     if (rc) return rc;
     double *P = (double *)ctx->ws;
-    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + p_bytes);
-    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + p_bytes + f_bytes);
+    double *thr[2] = {P + p_bytes / sizeof(double), P + 2 * (p_bytes / sizeof(double))};   // same shape as P
+    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 3 * p_bytes);
+    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 3 * p_bytes + f_bytes);
     {
         const int64_t items_f = (int64_t)g.GW * Nreg * NBLK, items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
@@ -431,13 +503,18 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
         hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
                            g.GW, r_T);
         FCD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(r_thr0_kernel, dim3((unsigned)U, (unsigned)g.GW), dim3(256), 0, s, thr[0], (int)U, (uint32_t)chain0,
+                           seed, (uint32_t)sweep);
+        FCD_LAUNCH_CHECK();
     }
     fcd_abl_refresh(s);
+    // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
+    const size_t per_u = ((size_t)NBLK * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
     int ub = 1;
-    while (ub < 4 && (size_t)(ub * 2) * row_bytes <= 64 * 1024 && ub * 2 <= U) ub *= 2;
+    while (ub < 4 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
     if (const char *e = getenv("FCD_R_UB")) {   // tuning knob: patients per panel workgroup (1, 2, 4)
         const int v = atoi(e);
-        if ((v == 1 || v == 2 || v == 4) && (size_t)v * row_bytes <= 160 * 1024) ub = v;
+        if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_u <= 156 * 1024) ub = v;
     }
     for (int b = 0; b < NBLK; ++b) {
         const int nb = (Nreg - b * R_NB < R_NB) ? (int)(Nreg - b * R_NB) : R_NB;
@@ -450,8 +527,8 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
             FCD_HIP_TRY(hipMemsetAsync(P, 0, p_bytes, s));
         }
         dim3 grid((unsigned)U, (unsigned)g.GW);
-        hipLaunchKernelGGL(gibbs_r_diag, grid, dim3(64 * D_WAVES), 0, s, lMd, hyper, f_r, r_T, r_bits, P, (int)Nreg, (int)U, NBLK,
-                           b, nb, (uint32_t)chain0, seed, (uint32_t)sweep);
+        hipLaunchKernelGGL(gibbs_r_diag, grid, dim3(64 * D_WAVES), 0, s, lMd, hyper, f_r, r_T, r_bits, P, thr[b & 1],
+                           thr[(b + 1) & 1], (int)Nreg, (int)U, NBLK, b, nb, (uint32_t)chain0, seed, (uint32_t)sweep);
         FCD_LAUNCH_CHECK();
     }
     return FCD_OK;

@@ -23,13 +23,67 @@ constexpr double kLogSqrt2Pi = 0.9189385332046727;   // numpy: log(sqrt(2*pi))
 
 constexpr int LIK_BLOCK = 256;
 
+// ---------------------------------------------------------------------------------------------
+// log for this kernel.  9 of the ~12 transcendental calls per (edge, patient) item are logs and the kernel
+// is ALU-bound on them (the ocml log is ~70 fp64 instructions), so a table-driven one (Tang 1990 style):
+//   x = 2^e * m, m in [0.75, 1.5);  i = top 6 mantissa bits;  r = fma(m, 1/m_i, -1), |r| <= 2^-6;
+//   log x = e*ln2 + log(m_i) + log1p(r),   log1p(r) by a degree-10 Taylor polynomial.
+// m_i = 1 for the two cells around 1, so there is no cancellation for x near 1.  Error <= ~1.5 ulp over the
+// whole positive range (subnormals included); log(0) = -inf as the reference's np.log gives for an
+// underflowed mixture density (fit.py:115, 121-122).  The 64-entry table {1/m_i, log m_i} lives in LDS.
+// ---------------------------------------------------------------------------------------------
+struct LogTab {
+    double inv[64];
+    double lg[64];
+};
+
+__device__ inline double fast_log(double x, const double2 *__restrict__ tab) {
+    if (!(x > 0.0)) return (x == 0.0) ? -__builtin_inf() : __builtin_nan("");
+    int eadj = 0;
+    if (x < 2.2250738585072014e-308) {   // subnormal: scale by 2^54
+        x *= 18014398509481984.0;
+        eadj = -54;
+    }
+    if (x == __builtin_inf()) return x;
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    const int idx = (int)((bits >> 46) & 63);            // top 6 mantissa bits
+    int e = (int)((bits >> 52) & 0x7FF) - 1023 + eadj;
+    // mantissa in [1, 2); cells 32..63 (m >= 1.5) are halved into [0.75, 1) and the exponent bumped
+    uint64_t mb = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    if (idx >= 32) {
+        mb -= 0x0010000000000000ull;
+        e += 1;
+    }
+    const double m = __longlong_as_double((long long)mb);
+    const double2 t = tab[idx];
+    const double r = fma(m, t.x, -1.0);
+    // log1p(r) = r - r^2/2 + r^3/3 - ... - r^10/10
+    double p = -0.1;
+    p = fma(p, r, 1.0 / 9.0);
+    p = fma(p, r, -0.125);
+    p = fma(p, r, 1.0 / 7.0);
+    p = fma(p, r, -1.0 / 6.0);
+    p = fma(p, r, 0.2);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    const double r2 = r * r;
+    const double de = (double)e;
+    const double hi = fma(de, 6.93147180369123816490e-01, t.y);        // e*ln2_hi + log m_i (ln2_hi has 32 trailing zero bits)
+    const double lo = fma(de, 1.90821492927058770002e-10, fma(p, r2, r));   // e*ln2_lo + log1p(r)
+    return hi + lo;
+}
+
 // One thread per (c,u) item; the block's 256 x 9 results are transposed through LDS so that the
 // 72-byte records leave as fully coalesced 16-byte-per-lane stores.
 __global__ __launch_bounds__(LIK_BLOCK) void lik_bt_kernel(const double *__restrict__ bt, int64_t n_items,
-                                                           LikTheta th, double *__restrict__ lM,
-                                                           double *__restrict__ pBt) {
+                                                           LikTheta th, const LogTab *__restrict__ logtab,
+                                                           double *__restrict__ lM, double *__restrict__ pBt) {
     __shared__ double stage[LIK_BLOCK * 9];
+    __shared__ double2 tab[64];
     const int tid = threadIdx.x;
+    if (tid < 64) tab[tid] = make_double2(logtab->inv[tid], logtab->lg[tid]);
+    __syncthreads();
     const int64_t n_tiles = (n_items + LIK_BLOCK - 1) / LIK_BLOCK;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * LIK_BLOCK;
@@ -55,7 +109,7 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_bt_kernel(const double *__restr
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
                     const double M = th.eps[l] * N[k] + th.omeps_half[l] * others[k];  // fit.py:430
-                    stage[tid * 9 + k * 3 + l] = log(M);                                // fit.py:122
+                    stage[tid * 9 + k * 3 + l] = fast_log(M, tab);                     // fit.py:122
                 }
             }
         }
@@ -139,7 +193,8 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     int64_t grid = n_tiles;
     const int64_t cap = (int64_t)ctx->num_cu * 8;  // 8 blocks of 256 threads per CU, grid-stride the rest
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(lik_bt_kernel, dim3((unsigned)grid), dim3(LIK_BLOCK), 0, s, bt, n_items, th, lM, p_Bt_g_Ft);
+    hipLaunchKernelGGL(lik_bt_kernel, dim3((unsigned)grid), dim3(LIK_BLOCK), 0, s, bt, n_items, th,
+                       reinterpret_cast<const LogTab *>(ctx->log_tab), lM, p_Bt_g_Ft);
     FCD_LAUNCH_CHECK();
     hipLaunchKernelGGL(lik_b_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, b, C, (int)H, th, S_B,
                        lp_B_g_F);

@@ -156,6 +156,15 @@ class GibbsEngine(object):
                       self.G, _lib.dptr(self.cnt_f), _lib.dptr(self.cnt_r), _lib.stream_ptr())
         self.n_accumulated += 1
 
+    def tally(self, want_counts=True, accumulate=True):
+        """stats() and accumulate() in one pass over the state; returns the counts tensor (or None)."""
+        self.ctx.call("fcd_gibbs_tally", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      _lib.dptr(self.counts if want_counts else None), _lib.dptr(self.cnt_f if accumulate else None),
+                      _lib.dptr(self.cnt_r if accumulate else None), _lib.stream_ptr())
+        if accumulate:
+            self.n_accumulated += 1
+        return self.counts if want_counts else None
+
     # ---- diagnostics ----
     def logjoint(self):
         out = self.torch.empty(self.G, dtype=self.torch.float64, device=self.f_state.device)
@@ -182,16 +191,17 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
 
     for each sweep: f step, r step; every `mstep_every` sweeps: pooled counts -> all-reduce over ranks ->
     M-step for (pi, gamma) on the device; after `burn_in` sweeps the marginal counters accumulate.
-    `engine` is anything with sweeps/stats/mstep/accumulate (the HIP engine here; the CPU tests pass an
+    `engine` is anything with sweeps/tally/mstep (the HIP engine here; the CPU tests pass an
     oracle-backed stand-in to exercise the multi-process logic under gloo).
     """
     for i in range(n_sweeps):
         s = sweep0 + i
         engine.sweeps(s, 1)
-        if update_theta and mstep_every > 0 and (i + 1) % mstep_every == 0:
-            counts = allreduce_counts(engine.stats(), group)
-            engine.mstep(counts)
-        if i >= burn_in:
-            engine.accumulate()
+        do_m = bool(update_theta and mstep_every > 0 and (i + 1) % mstep_every == 0)
+        do_a = i >= burn_in
+        if do_m or do_a:
+            counts = engine.tally(want_counts=do_m, accumulate=do_a)    # one pass over the state for both
+            if do_m:
+                engine.mstep(allreduce_counts(counts, group))
         if on_sweep is not None:
             on_sweep(i, engine)

@@ -158,6 +158,10 @@ int fcd_gibbs_mstep(fcd_ctx *ctx, const int64_t *counts, int64_t Nreg, int64_t U
  * (uint32, device); posterior marginals = counts / (sweeps * G). */
 int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
                          int64_t U, int64_t G, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
+/* fcd_gibbs_stats and fcd_gibbs_accumulate in ONE pass over the state (what the sampler loop calls):
+ * counts (nullable) is overwritten as by fcd_gibbs_stats; cnt_f / cnt_r (both or neither) are incremented. */
+int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                    int64_t G, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
 /* log p(f, r, b, bt; theta) of each chain = minus the first four terms of fit.py:149-152 at one-hot q.
  * out (G,) doubles. */
 int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,

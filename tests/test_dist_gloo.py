@@ -1,7 +1,7 @@
 """
 The multi-process path on CPU: 2 ranks, gloo, 127.0.0.1.
 
-The product sampler loop (fcdiff_amd.gibbs.run_chains) only needs an object with sweeps/stats/mstep/accumulate;
+The product sampler loop (fcdiff_amd.gibbs.run_chains) only needs an object with sweeps/tally/mstep;
 on a GPU that is the HIP engine.  Here an oracle-backed stand-in (C restatement, tests only) takes its place so
 that what runs under gloo is exactly the distributed logic: global chain ids per rank, the all-reduce of the
 pooled counts, the shared (pi, gamma) M-step.  Two ranks with 5 + 4 chains must reproduce one process with 9.
@@ -52,6 +52,11 @@ class OracleEngine(object):
     def accumulate(self):
         self.cnt_r += self.r.sum(axis=0, dtype=np.int64)
         self.n_acc += 1
+
+    def tally(self, want_counts=True, accumulate=True):
+        if accumulate:
+            self.accumulate()
+        return self.stats() if want_counts else None
 
 
 def problem():

@@ -112,6 +112,35 @@ def test_lik_tables_underflow_gives_minus_inf_like_reference(env):
     nptest.assert_allclose(got[fin], lM[fin], **TAB)
 
 
+def test_lik_tables_wide_dynamic_range(env):
+    """
+    K_lik uses its own table-driven log (fcd_lik.hip): sweep the mixture density over its whole range --
+    from ~40 down through the subnormals to exact underflow -- and compare with NumPy's log in the oracle.
+    """
+    m = env.pkg.UnsharedRegionModel()
+    m.sigma = np.array([0.0211, 0.0207, 0.0219])
+    (N, H, U) = (10, 2, 89)
+    C = 45
+    bt = np.linspace(-1.0, 1.0, C * U).reshape(C, U)
+    bt[3, 5] = m.mu[1]                      # exactly at a mode
+    b = np.zeros((C, H))
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    with np.errstate(divide="ignore"):
+        _, pBt, lM = env.O.lik_tables(b, bt, m.mu, m.sigma, m.eta, m.epsilon)
+    got = fit._lM
+    assert np.isneginf(lM).any() and (lM > 2).any() and ((lM < -700) & np.isfinite(lM)).any()
+    assert np.array_equal(np.isneginf(got), np.isneginf(lM))
+    fin = np.isfinite(lM)
+    nptest.assert_allclose(got[fin], lM[fin], rtol=5e-13, atol=2e-15)
+    # near M = 1 (log ~ 0) there is no cancellation: absolute error stays at the 1e-16 level
+    near1 = fin & (np.abs(lM) < 0.05)
+    if near1.any():
+        assert np.max(np.abs(got[near1] - lM[near1])) < 5e-16
+
+
 def test_lik_tables_cfg3_size(env):
     """BASELINE cfg 3 shape (Nreg=200, H=U=50) against the C oracle."""
     (N, H, U) = (200, 50, 50)
@@ -392,6 +421,16 @@ def test_gibbs_mstep_and_accumulate(env):
         cr += r.sum(axis=0, dtype=np.int64)
     nptest.assert_array_equal(eng.cnt_f.cpu().numpy(), cf)
     nptest.assert_array_equal(eng.cnt_r.cpu().numpy(), cr)
+    # the fused pass (what the sampler loop calls) = stats() + accumulate()
+    ref_counts = eng.stats().cpu().numpy().copy()
+    t_counts = eng.tally(want_counts=True, accumulate=True).cpu().numpy()
+    nptest.assert_array_equal(t_counts[:5], ref_counts[:5])
+    for k in range(3):
+        cf[:, k] += (f == k).sum(axis=0)
+    cr += r.sum(axis=0, dtype=np.int64)
+    nptest.assert_array_equal(eng.cnt_f.cpu().numpy(), cf)
+    nptest.assert_array_equal(eng.cnt_r.cpu().numpy(), cr)
+    assert eng.n_accumulated == 4
     counts = eng.stats()
     c = counts.cpu().numpy()
     assert c[4] == G and c[1] + c[2] + c[3] == G * eng.C and c[0] == r.sum()
