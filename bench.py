@@ -82,20 +82,18 @@ def main():
     fit._update_lps()                                                     # K_lik
     torch.cuda.synchronize()
 
-    # K_lik timed on its own (it runs once per theta_sub change, outside the sweep loop)
-    lik_ms = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    ctx = fit._context()
+    # K_lik timed on its own (it runs once per theta_sub change, outside the sweep loop): one launch, events on its stream
+    ctx.prof_enable(True)
+    for _ in range(10):
         fit._update_lps()
-        e1.record()
-        torch.cuda.synchronize()
-        lik_ms.append(e0.elapsed_time(e1))
-    lik_ms = float(np.median(lik_ms))
+    torch.cuda.synchronize()
+    (lik_tot, lik_n) = ctx.prof_collect()["lik_kernel"]
+    lik_ms = lik_tot / max(lik_n, 1)
     lik_bytes = 8 * C * (H + U) + 24 * C + 72 * C * U
+    ctx.prof_enable(False)
 
-    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, chain0=chain0, seed=seed, edge_index="symmetric",
-                      ctx=fit._context())
+    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, chain0=chain0, seed=seed, edge_index="symmetric", ctx=ctx)
     eng.set_hyper(model.gamma, model.pi2())
     eng.init(float(model.pi))
 
@@ -136,15 +134,39 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # Per-kernel durations: one HIP event pair around EVERY f / panel / diagonal launch costs ~3.7 us per event
+    # (54 per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right
+    # after it with the pairs enabled, and only that second pass feeds the per-kernel numbers.
+    ctx.prof_enable(True)
+    for s in range(args.warmup + args.steps, args.warmup + 2 * args.steps):
+        step(s, False)
+    torch.cuda.synchronize()
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
 
-    f_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["f"]]))
-    r_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["r"]]))
-    # algorithmic bytes per launch, SURVEY.md section 8d (u8 state): lM once per pass + state
+    f_pass_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["f"]]))
+    r_pass_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["r"]]))
+    kern = {k: {"total_ms": v[0], "launches": v[1], "avg_launch_ms": v[0] / max(v[1], 1)} for (k, v) in prof.items()
+            if k != "lik_kernel"}
+    # algorithmic bytes, SURVEY.md section 8d (u8 state): lM once per pass + state
     f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
     r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
-    (dom, dom_ms, dom_bytes) = ("gibbs_r_kernel", r_ms, r_bytes) if r_ms >= f_ms else ("gibbs_f_kernel", f_ms, f_bytes)
+    n_panel = max(kern["gibbs_r_panel"]["launches"] // max(args.steps, 1), 1)     # panel launches per pass
+    per_launch_bytes = {"gibbs_f_pair_kernel": f_bytes,
+                        # a panel launch serves 16 of the Nreg regions' rows of the r pass
+                        "gibbs_r_panel": r_bytes / n_panel,
+                        "gibbs_r_diag": 0.0}
+    dom = max(("gibbs_f_pair_kernel", "gibbs_r_panel"), key=lambda k: kern[k]["total_ms"])
+    dom_ms = kern[dom]["avg_launch_ms"]
+    dom_bytes = per_launch_bytes[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    adds = (3 if dom == "gibbs_f_kernel" else 4) * C * U * G
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")    # HBM bytes per launch from the PMC passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
 
     out = {
         "metric": "posterior samples/sec at R=200 ROIs, N=100 subj, 1024 chains; 1/2/4/8 GPUs",
@@ -164,16 +186,21 @@ def main():
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                     "note": "tables are shared by all chains and stay in the 256 MiB Infinity Cache at this size, so "
-                             "the sweep is fp64-VALU/LDS bound, not HBM bound (SURVEY 8d); fp64 adds/s below",
-                     "f64_adds_per_s": adds / (dom_ms * 1e-3)},
-        "kernels_ms": {"gibbs_f_kernel": f_ms, "gibbs_r_kernel": r_ms},
-        "lik_tables": {"bound": "hbm", "algorithmic_bytes": lik_bytes, "ms": lik_ms,
+                     "launches_timed": kern[dom]["launches"],
+                     "note": "dominant kernel by total time; HIP event pair around every launch (fcd_prof_*) in a second "
+                             "pass of the same K steps right after the timed region (the pairs would perturb it). The tables "
+                             "are shared by all chains and stay in L2 / Infinity Cache at this size, so the sweep is bound by "
+                             "wave-wide LDS reads, not by HBM (DESIGN.md section e, profiles/r01_ubench_lds_fp64.txt)"},
+        "kernels": kern,
+        "passes_ms": {"f_pass": f_pass_ms, "r_pass": r_pass_ms,
+                      "f_pass_GBps": f_bytes / (f_pass_ms * 1e-3) / 1e9, "r_pass_GBps": r_bytes / (r_pass_ms * 1e-3) / 1e9,
+                      "f64_adds_per_s": (2 * C * U * G + 2 * C * U * G) / ((f_pass_ms + r_pass_ms) * 1e-3)},
+        "lik_tables": {"kernel": "lik_kernel", "bound": "hbm", "algorithmic_bytes": lik_bytes, "avg_launch_ms": lik_ms,
                        "achieved": lik_bytes / (lik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": lik_bytes / (lik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "note": "two launches (bt->lM, b->S_B) timed together with HIP events"},
+                       "note": "one launch; event pair on its stream, mean of %d launches" % lik_n},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

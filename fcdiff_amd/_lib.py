@@ -35,6 +35,8 @@ SIGNATURES = {
     "fcd_ctx_create": (_int, [C.POINTER(_p)]),
     "fcd_ctx_destroy": (_int, [_p]),
     "fcd_ctx_reserve": (_int, [_p, _i64, _i64, _i64]),
+    "fcd_prof_enable": (_int, [_p, _int]),
+    "fcd_prof_collect": (_int, [_p, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     "fcd_N_to_C": (_i64, [_i64]),
     "fcd_C_to_N": (_i64, [_i64]),
     "fcd_nm_to_c": (_i64, [_i64, _i64]),
@@ -138,6 +140,20 @@ class Context(object):
 
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args), self.handle)
+
+    PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_panel": 2, "gibbs_r_diag": 3}
+
+    def prof_enable(self, on=True):
+        self.call("fcd_prof_enable", 1 if on else 0)
+
+    def prof_collect(self):
+        """{kernel: (total_ms, launches)} of the event pairs recorded since the last collect."""
+        out = {}
+        for name, slot in self.PROF_SLOTS.items():
+            (ms, n) = (_dbl(), _i64())
+            self.call("fcd_prof_collect", slot, C.byref(ms), C.byref(n))
+            out[name] = (ms.value, n.value)
+        return out
 
 
 def stream_ptr():

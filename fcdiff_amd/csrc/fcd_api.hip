@@ -28,7 +28,51 @@ int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes) {
     return FCD_OK;
 }
 
+void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s) {
+    if (!ctx->prof_on) return;
+    if (ctx->prof_n[slot] >= ctx->prof_cap[slot]) {
+        const int cap = ctx->prof_cap[slot] ? ctx->prof_cap[slot] * 2 : 256;
+        hipEvent_t *ev = new (std::nothrow) hipEvent_t[2 * cap];
+        if (!ev) return;
+        for (int i = 0; i < 2 * ctx->prof_cap[slot]; ++i) ev[i] = ctx->prof_ev[slot][i];
+        for (int i = 2 * ctx->prof_cap[slot]; i < 2 * cap; ++i)
+            if (hipEventCreate(&ev[i]) != hipSuccess) { delete[] ev; return; }
+        delete[] ctx->prof_ev[slot];
+        ctx->prof_ev[slot] = ev;
+        ctx->prof_cap[slot] = cap;
+    }
+    (void)hipEventRecord(ctx->prof_ev[slot][2 * ctx->prof_n[slot]], s);
+}
+
+void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s) {
+    if (!ctx->prof_on || ctx->prof_n[slot] >= ctx->prof_cap[slot]) return;
+    (void)hipEventRecord(ctx->prof_ev[slot][2 * ctx->prof_n[slot] + 1], s);
+    ctx->prof_n[slot] += 1;
+}
+
 extern "C" {
+
+int fcd_prof_enable(fcd_ctx *ctx, int on) {
+    if (!ctx) return FCD_ERR_ARG;
+    ctx->prof_on = on ? 1 : 0;
+    for (int i = 0; i < FCD_PROF_SLOTS; ++i) ctx->prof_n[i] = 0;
+    return FCD_OK;
+}
+
+int fcd_prof_collect(fcd_ctx *ctx, int slot, double *total_ms, int64_t *count) {
+    if (!ctx || slot < 0 || slot >= FCD_PROF_SLOTS || !total_ms || !count) return FCD_ERR_ARG;
+    double tot = 0.0;
+    for (int i = 0; i < ctx->prof_n[slot]; ++i) {
+        FCD_HIP_TRY(hipEventSynchronize(ctx->prof_ev[slot][2 * i + 1]));
+        float ms = 0.f;
+        FCD_HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[slot][2 * i], ctx->prof_ev[slot][2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = ctx->prof_n[slot];
+    ctx->prof_n[slot] = 0;
+    return FCD_OK;
+}
 
 int fcd_abi_version(void) { return FCD_ABI_VERSION; }
 
@@ -61,6 +105,11 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->log_tab = nullptr;
+    ctx->prof_on = 0;
+    for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
+        ctx->prof_ev[i] = nullptr;
+        ctx->prof_n[i] = ctx->prof_cap[i] = 0;
+    }
     ctx->msg[0] = 0;
     int rc = fcd_ws_reserve(ctx, 1u << 20);
     if (rc) {
@@ -94,6 +143,10 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     hipError_t e = hipSuccess;
     if (ctx->ws) e = hipFree(ctx->ws);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
+    for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
+        for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
+        delete[] ctx->prof_ev[i];
+    }
     delete ctx;
     return (int)e;
 }
@@ -105,7 +158,7 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
     const size_t en = (size_t)ctx->num_cu * 8 * 8 * sizeof(double);  // energy partials
     if (en > need) need = en;
     const int64_t NBLK = (Nreg + 15) / 16;
-    const size_t panel = 3 * (size_t)GW * U * 16 * 64 * sizeof(double)     // r step: per-block partial sums + 2 threshold buffers,
+    const size_t panel = 10 * (size_t)GW * U * 16 * 64 * sizeof(double)    // r step: partial sums of a superblock + 2 threshold buffers,
                          + (size_t)GW * Nreg * NBLK * 64 * 4                // packed f,
                          + (size_t)GW * U * NBLK * 64 * 2 + 512;            // per-lane r words
     if (panel > need) need = panel;

@@ -7,12 +7,23 @@
 
 #include "../../include/fcdiff_hip.h"
 
+#define FCD_PROF_SLOTS 4
+#define FCD_PROF_LIK 0
+#define FCD_PROF_F 1
+#define FCD_PROF_PANEL 2
+#define FCD_PROF_DIAG 3
+
 struct fcd_ctx {
     int device;
     int num_cu;
     void *ws;          // reduction / partial-sum workspace
     size_t ws_bytes;
     void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
+    // optional per-kernel timing with HIP events on the launch stream (fcd_prof_enable / fcd_prof_collect)
+    int prof_on;
+    hipEvent_t *prof_ev[FCD_PROF_SLOTS];   // pairs (begin, end)
+    int prof_n[FCD_PROF_SLOTS];            // pairs recorded
+    int prof_cap[FCD_PROF_SLOTS];
     char msg[256];
 };
 
@@ -34,6 +45,9 @@ static inline int fcd_fail(fcd_ctx *ctx, int code, const char *fmt, long long a 
 }
 
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
+// bracket ONE kernel launch with events when profiling is on (no-ops otherwise)
+void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s);
+void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s);
 
 // hyper block offsets
 #define FCD_H_LNGAMMA 0

@@ -733,12 +733,14 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem);
             if (err != hipSuccess) return (int)err;
         }
+        fcd_prof_begin(ctx, FCD_PROF_F, s);
         if (NW32 == 1)
             hipLaunchKernelGGL(gibbs_f_pair_kernel<1>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
                                (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
         else
             hipLaunchKernelGGL(gibbs_f_pair_kernel<2>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
                                (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
+        fcd_prof_end(ctx, FCD_PROF_F, s);
         FCD_LAUNCH_CHECK();
         return FCD_OK;
     }

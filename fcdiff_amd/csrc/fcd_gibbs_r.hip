@@ -104,18 +104,19 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
 // built in LDS from the two single rows while staging.  One 8-byte LDS read and one fp64 add then cover
 // TWO regions; the address is  q*32 + tt*8  from the packed f / r words (2 integer ops per term + 2 per pair).
 // LDS: singles [UB][Nreg*6] doubles (scratch) + pairs [8*NBLK][UB][36] doubles.
-// P[((w*U + u)*R_NB + i)][lane], i = n - 16 b_own.
 // ---------------------------------------------------------------------------------------------
 constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
 template <int UB>
 __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__ lMd, const uint32_t *__restrict__ f_r,
                                                       const uint16_t *__restrict__ r_T, double *__restrict__ P, int Nreg,
-                                                      int U, int NBLK, int GW, int b_own, int nb) {
+                                                      int U, int NBLK, int GW, int sb0, int sb1, int prow) {
+    // One launch serves a SUPERBLOCK: the blocks sb0 .. sb1-1 of 16 regions.  grid.x = its regions; all its blocks
+    // are left out of the sums (gibbs_r_diag adds them, in order).  P[((w*U + u)*prow + i)][lane], i = n - 16 sb0.
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
     double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][Nreg*6]
-    const int n = b_own * R_NB + blockIdx.x;
+    const int n = sb0 * R_NB + blockIdx.x;
     const int u0 = blockIdx.y * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
     {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
             const int b = bg + g;
-            if (b >= NBLK || b == b_own) continue;
+            if (b >= NBLK || (b >= sb0 && b < sb1)) continue;
             if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g] + rwv[g][0] + rwv[g][UB - 1]); continue; }   // ablation: loads only
             const uint32_t fp = fpv[g];
             const uint32_t base = (uint32_t)b * ((R_NB / 2) * REC);
@@ -210,10 +211,10 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
             for (int u = 0; u < UB; ++u) rwv[g][u] = rwn[g][u];
         }
     }
-    const int i = n - b_own * R_NB;
+    const int i = n - sb0 * R_NB;
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-        if (u < nu) P[(((int64_t)w * U + u0 + u) * R_NB + i) * 64 + lane] = d[u];
+        if (u < nu) P[(((int64_t)w * U + u0 + u) * prow + i) * 64 + lane] = d[u];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
                                                              const uint32_t *__restrict__ f_r, uint16_t *__restrict__ r_T,
                                                              uint64_t *__restrict__ r_bits, const double *__restrict__ P,
                                                              const double *__restrict__ thr_cur, double *__restrict__ thr_next,
-                                                             int Nreg, int U, int NBLK, int b_own, int nb,
-                                                             uint32_t chain0, uint64_t seed, uint32_t sweep) {
+                                                             int Nreg, int U, int NBLK, int b_own, int nb, int sb0, int sb1,
+                                                             int prow, uint32_t chain0, uint64_t seed, uint32_t sweep) {
     __shared__ double tile[R_NB * R_NB * 6];   // [i][j][k][t]
     __shared__ double sh_d[R_NB][64];
     __shared__ uint32_t sh_fp[R_NB][64];
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
     const int64_t wu = (int64_t)w * U + u;
     uint16_t *__restrict__ rTw = r_T + (wu * NBLK + b_own) * 64 + lane;
     const uint32_t old = *rTw;
-    const double *__restrict__ Pw = P + (wu * R_NB) * 64 + lane;
+    const double *__restrict__ Pw = P + (wu * prow + (b_own - sb0) * R_NB) * 64 + lane;
     const uint32_t *__restrict__ frw = f_r + (((int64_t)w * Nreg + B0) * NBLK + b_own) * 64 + lane;
     const char *tb = reinterpret_cast<const char *>(tile);
 
@@ -287,6 +288,30 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
         const bool on = i < nb;
         fp[a] = on ? frw[(int64_t)i * NBLK * 64] : 0u;
         d[a] = on ? Pw[i * 64] : 0.0;
+    }
+    // The other blocks of the superblock (left out of the panel): whatever r_T holds for them IS the value the scan
+    // needs -- already redrawn for earlier blocks, still old for later ones.  Their 16 terms per row come straight
+    // from the table in L2 (64 independent 8-byte gathers per wave and block: all issued, then added).
+    for (int bo = sb0; bo < sb1; ++bo) {
+        if (bo == b_own) continue;
+        const uint32_t ro = rTw[(int64_t)(bo - b_own) * 64];
+        const int mo = (Nreg - bo * R_NB < R_NB) ? (Nreg - bo * R_NB) : R_NB;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = q + 4 * a;
+            if (i < nb) {
+                const uint32_t fo = frw[(int64_t)i * NBLK * 64 + (int64_t)(bo - b_own) * 64];
+                const char *row = reinterpret_cast<const char *>(lMd + (((int64_t)u * Nreg + B0 + i) * Nreg + bo * R_NB) * 6);
+                double tmp[R_NB];
+#pragma unroll
+                for (int j = 0; j < R_NB; ++j) {
+                    const uint32_t t = (ro >> j) & 1u;
+                    tmp[j] = (j < mo) ? *reinterpret_cast<const double *>(row + j * 48 + (f_of(fo, j) << 4) + (t << 3)) : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < R_NB; ++j) d[a] += tmp[j];
+            }
+        }
     }
     double thr[R_NB];
     if (q == 0) {
@@ -423,8 +448,8 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
 }
 
 template <int UB>
-int launch_panel(const double *lMd, const uint32_t *f_r, const uint16_t *r_T, double *P, int64_t Nreg, int64_t U, int NBLK,
-                 const fcd_geo &g, int b_own, int nb, hipStream_t s) {
+int launch_panel(fcd_ctx *ctx, const double *lMd, const uint32_t *f_r, const uint16_t *r_T, double *P, int64_t Nreg, int64_t U, int NBLK,
+                 const fcd_geo &g, int sb0, int sb1, int n_rows, int prow, hipStream_t s) {
     const int wpb = g.GW < 16 ? g.GW : 16;
     const size_t shmem = ((size_t)NBLK * (R_NB / 2) * UB * 36 + (size_t)UB * Nreg * 6) * sizeof(double);
     if (shmem > 64 * 1024) {
@@ -432,9 +457,11 @@ int launch_panel(const double *lMd, const uint32_t *f_r, const uint16_t *r_T, do
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid((unsigned)nb, (unsigned)((U + UB - 1) / UB), (unsigned)((g.GW + wpb - 1) / wpb));
+    dim3 grid((unsigned)n_rows, (unsigned)((U + UB - 1) / UB), (unsigned)((g.GW + wpb - 1) / wpb));
+    fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
     hipLaunchKernelGGL(gibbs_r_panel<UB>, grid, dim3(64 * wpb), shmem, s, lMd, f_r, r_T, P, (int)Nreg, (int)U, NBLK, g.GW,
-                       b_own, nb);
+                       sb0, sb1, prow);
+    fcd_prof_end(ctx, FCD_PROF_PANEL, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -484,17 +511,18 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     }
     // blocked path.  Workspace: P | f_r | r_T
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
-    const size_t p_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);
+    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one threshold buffer
+    const size_t p_bytes = 8 * t_bytes;                                          // P: up to 8 blocks per superblock
     const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint32_t);
     const size_t r_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t);
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, 3 * p_bytes + f_bytes + r_bytes + 512);
+    rc = fcd_ws_reserve(ctx, p_bytes + 2 * t_bytes + f_bytes + r_bytes + 512);
     if (rc) return rc;
     double *P = (double *)ctx->ws;
-    double *thr[2] = {P + p_bytes / sizeof(double), P + 2 * (p_bytes / sizeof(double))};   // same shape as P
-    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 3 * p_bytes);
-    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 3 * p_bytes + f_bytes);
+    double *thr[2] = {P + p_bytes / sizeof(double), P + (p_bytes + t_bytes) / sizeof(double)};
+    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + p_bytes + 2 * t_bytes);
+    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + p_bytes + 2 * t_bytes + f_bytes);
     {
         const int64_t items_f = (int64_t)g.GW * Nreg * NBLK, items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
@@ -510,26 +538,42 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
     const size_t per_u = ((size_t)NBLK * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
+    // (2 patients: two workgroups fit a CU, whose staging / pair-build / term phases then overlap; measured best at cfg3)
     int ub = 1;
-    while (ub < 4 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
+    while (ub < 2 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
     if (const char *e = getenv("FCD_R_UB")) {   // tuning knob: patients per panel workgroup (1, 2, 4)
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_u <= 156 * 1024) ub = v;
     }
-    for (int b = 0; b < NBLK; ++b) {
-        const int nb = (Nreg - b * R_NB < R_NB) ? (int)(Nreg - b * R_NB) : R_NB;
-        if (NBLK > 1) {   // something outside the block
-            if (ub == 4) rc = launch_panel<4>(lMd, f_r, r_T, P, Nreg, U, NBLK, g, b, nb, s);
-            else if (ub == 2) rc = launch_panel<2>(lMd, f_r, r_T, P, Nreg, U, NBLK, g, b, nb, s);
-            else rc = launch_panel<1>(lMd, f_r, r_T, P, Nreg, U, NBLK, g, b, nb, s);
+    // Superblocks of SB blocks: one panel launch per superblock, then its diagonal kernels in order (each adds the
+    // other blocks of its superblock itself).  SB = 1 measured best at cfg3 (598 us vs 631 / 739 for SB = 2 / 4).
+    int SB = 1;
+    if (const char *e = getenv("FCD_R_SB")) {   // tuning knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) SB = v;
+    }
+    const int prow = SB * R_NB;
+    for (int sb0 = 0; sb0 < NBLK; sb0 += SB) {
+        const int sb1 = (sb0 + SB < NBLK) ? sb0 + SB : NBLK;
+        const int n_rows = (int)(((int64_t)sb1 * R_NB < Nreg ? (int64_t)sb1 * R_NB : Nreg) - (int64_t)sb0 * R_NB);
+        if (sb0 > 0 || sb1 < NBLK) {   // something outside the superblock
+            if (ub == 4) rc = launch_panel<4>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
+            else if (ub == 2) rc = launch_panel<2>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
+            else rc = launch_panel<1>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
             if (rc) return rc;
         } else {
-            FCD_HIP_TRY(hipMemsetAsync(P, 0, p_bytes, s));
+            FCD_HIP_TRY(hipMemsetAsync(P, 0, (size_t)g.GW * U * prow * 64 * sizeof(double), s));
         }
-        dim3 grid((unsigned)U, (unsigned)g.GW);
-        hipLaunchKernelGGL(gibbs_r_diag, grid, dim3(64 * D_WAVES), 0, s, lMd, hyper, f_r, r_T, r_bits, P, thr[b & 1],
-                           thr[(b + 1) & 1], (int)Nreg, (int)U, NBLK, b, nb, (uint32_t)chain0, seed, (uint32_t)sweep);
-        FCD_LAUNCH_CHECK();
+        for (int b = sb0; b < sb1; ++b) {
+            const int nb = (Nreg - b * R_NB < R_NB) ? (int)(Nreg - b * R_NB) : R_NB;
+            dim3 grid((unsigned)U, (unsigned)g.GW);
+            fcd_prof_begin(ctx, FCD_PROF_DIAG, s);
+            hipLaunchKernelGGL(gibbs_r_diag, grid, dim3(64 * D_WAVES), 0, s, lMd, hyper, f_r, r_T, r_bits, P, thr[b & 1],
+                               thr[(b + 1) & 1], (int)Nreg, (int)U, NBLK, b, nb, sb0, sb1, prow, (uint32_t)chain0, seed,
+                               (uint32_t)sweep);
+            fcd_prof_end(ctx, FCD_PROF_DIAG, s);
+            FCD_LAUNCH_CHECK();
+        }
     }
     return FCD_OK;
 }

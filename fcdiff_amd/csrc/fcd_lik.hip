@@ -1,7 +1,7 @@
 // K_lik: the per-edge likelihood tables of UnsharedRegionFit._update_lps (fcdiff/fit.py:104-122)
 // with _eval_M / _eval_M_eps (fit.py:409-444) fused in.
 //
-// Streaming, HBM-bound: reads b (C,H) and bt (C,U) once, writes S_B (C,3) and lM (C,U,3,3) once.
+// Streaming: reads b (C,H) and bt (C,U) once, writes S_B (C,3) and lM (C,U,3,3) once, in ONE launch.
 // Algorithmic bytes per call = 8*C*(H+U) + 24*C + 72*C*U  (SURVEY.md section 8d).
 //
 // The (C,H,3) table of the reference is never consumed except through its H-sum (fit.py:171, :472),
@@ -13,6 +13,7 @@ namespace {
 struct LikTheta {
     double mu[3];
     double sigma[3];
+    double pdf_scale[3];   // 1 / sqrt(2 pi) / sigma_k  (the reference's two divisions applied to 1.0)
     double lnsigma[3];
     double eps[3];       // _eval_M_eps(eta, epsilon, l), l = 0,1,2
     double omeps_half[3];  // (1 - eps_l) * 0.5, the reference's evaluation order
@@ -74,18 +75,56 @@ __device__ inline double fast_log(double x, const double2 *__restrict__ tab) {
     return hi + lo;
 }
 
-// One thread per (c,u) item; the block's 256 x 9 results are transposed through LDS so that the
-// 72-byte records leave as fully coalesced 16-byte-per-lane stores.
-__global__ __launch_bounds__(LIK_BLOCK) void lik_bt_kernel(const double *__restrict__ bt, int64_t n_items,
-                                                           LikTheta th, const LogTab *__restrict__ logtab,
-                                                           double *__restrict__ lM, double *__restrict__ pBt) {
+// One launch, two kinds of blocks.
+// Blocks [0, n_bt_blocks): one thread per (c,u) item; the block's 256 x 9 results are transposed through LDS so that
+//   the 72-byte records leave as fully coalesced 16-byte-per-lane stores (grid-stride over tiles of 256 items).
+// Blocks [n_bt_blocks, ...): 16 lanes per edge, S_B[c,k] = sum_h ( -z*z/2 - log(sqrt(2 pi)) - log(sigma_k) )  (fit.py:114, :171)
+__global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict__ bt, int64_t n_items, LikTheta th,
+                                                        const LogTab *__restrict__ logtab, double *__restrict__ lM,
+                                                        double *__restrict__ pBt, int n_bt_blocks,
+                                                        const double *__restrict__ b, int64_t C, int H,
+                                                        double *__restrict__ S_B, double *__restrict__ lpB) {
     __shared__ double stage[LIK_BLOCK * 9];
     __shared__ double2 tab[64];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_bt_blocks) {
+        const int sub = tid & 15;
+        const int64_t c = (int64_t)(blockIdx.x - n_bt_blocks) * 16 + (tid >> 4);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (c < C) {
+            const double *row = b + c * H;
+            for (int h = sub; h < H; h += 16) {
+                const double x = row[h];
+                const double z0 = (x - th.mu[0]) / th.sigma[0];
+                const double z1 = (x - th.mu[1]) / th.sigma[1];
+                const double z2 = (x - th.mu[2]) / th.sigma[2];
+                const double l0 = -(z0 * z0) / 2.0 - kLogSqrt2Pi - th.lnsigma[0];
+                const double l1 = -(z1 * z1) / 2.0 - kLogSqrt2Pi - th.lnsigma[1];
+                const double l2 = -(z2 * z2) / 2.0 - kLogSqrt2Pi - th.lnsigma[2];
+                if (lpB) {
+                    double *o = lpB + (c * H + h) * 3;
+                    o[0] = l0; o[1] = l1; o[2] = l2;
+                }
+                s0 += l0; s1 += l1; s2 += l2;
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 16);
+            s1 += __shfl_xor(s1, o, 16);
+            s2 += __shfl_xor(s2, o, 16);
+        }
+        if (c < C && sub == 0) {
+            S_B[c * 3 + 0] = s0;
+            S_B[c * 3 + 1] = s1;
+            S_B[c * 3 + 2] = s2;
+        }
+        return;
+    }
     if (tid < 64) tab[tid] = make_double2(logtab->inv[tid], logtab->lg[tid]);
     __syncthreads();
     const int64_t n_tiles = (n_items + LIK_BLOCK - 1) / LIK_BLOCK;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += n_bt_blocks) {
         const int64_t base = tile * LIK_BLOCK;
         const int64_t i = base + tid;
         if (i < n_items) {
@@ -93,9 +132,16 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_bt_kernel(const double *__restr
             double N[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                // scipy.stats.norm.pdf: exp(-z*z/2) / sqrt(2 pi) / sigma   (fit.py:115)
+                // scipy.stats.norm.pdf: exp(-z*z/2) / sqrt(2 pi) / sigma   (fit.py:115).  z keeps the reference's
+                // division (the exponent decides WHERE the density underflows to 0, i.e. where lM = -inf, and that
+                // pattern must match); the two divisions of the result are one multiplication by a host-side
+                // 1/sqrt(2 pi)/sigma (<= 1 ulp of the density): the kernel is ALU-bound, fp64 division ~15 instructions.
                 const double z = (x - th.mu[k]) / th.sigma[k];
-                N[k] = exp(-(z * z) / 2.0) / kSqrt2Pi / th.sigma[k];
+                const double e = exp(-(z * z) / 2.0);
+                N[k] = e * th.pdf_scale[k];
+                // at the edge of the double range the reference's two roundings decide whether the density is 0
+                // (lM = -inf) or a subnormal: redo exactly its operations there (rare, wave-divergent only then)
+                if (N[k] < 1e-290) N[k] = e / kSqrt2Pi / th.sigma[k];
             }
             if (pBt) {
                 pBt[i * 3 + 0] = N[0];
@@ -127,42 +173,6 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_bt_kernel(const double *__restr
     }
 }
 
-// 16 lanes per edge: S_B[c,k] = sum_h ( -z*z/2 - log(sqrt(2 pi)) - log(sigma_k) )  (fit.py:114, :171)
-__global__ __launch_bounds__(256) void lik_b_kernel(const double *__restrict__ b, int64_t C, int H, LikTheta th,
-                                                    double *__restrict__ S_B, double *__restrict__ lpB) {
-    const int sub = threadIdx.x & 15;
-    const int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        const double *row = b + c * H;
-        for (int h = sub; h < H; h += 16) {
-            const double x = row[h];
-            const double z0 = (x - th.mu[0]) / th.sigma[0];
-            const double z1 = (x - th.mu[1]) / th.sigma[1];
-            const double z2 = (x - th.mu[2]) / th.sigma[2];
-            const double l0 = -(z0 * z0) / 2.0 - kLogSqrt2Pi - th.lnsigma[0];
-            const double l1 = -(z1 * z1) / 2.0 - kLogSqrt2Pi - th.lnsigma[1];
-            const double l2 = -(z2 * z2) / 2.0 - kLogSqrt2Pi - th.lnsigma[2];
-            if (lpB) {
-                double *o = lpB + (c * H + h) * 3;
-                o[0] = l0; o[1] = l1; o[2] = l2;
-            }
-            s0 += l0; s1 += l1; s2 += l2;
-        }
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o, 16);
-        s1 += __shfl_xor(s1, o, 16);
-        s2 += __shfl_xor(s2, o, 16);
-    }
-    if (c < C && sub == 0) {
-        S_B[c * 3 + 0] = s0;
-        S_B[c * 3 + 1] = s1;
-        S_B[c * 3 + 2] = s2;
-    }
-}
-
 }  // namespace
 
 extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, int64_t C, int64_t H, int64_t U,
@@ -177,6 +187,7 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     for (int k = 0; k < 3; ++k) {
         th.mu[k] = theta[6 + k];
         th.sigma[k] = theta[9 + k];
+        th.pdf_scale[k] = 1.0 / kSqrt2Pi / theta[9 + k];
         th.lnsigma[k] = log(theta[9 + k]);
     }
     // _eval_M_eps, fit.py:433-444 (same operation order)
@@ -193,11 +204,11 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     int64_t grid = n_tiles;
     const int64_t cap = (int64_t)ctx->num_cu * 8;  // 8 blocks of 256 threads per CU, grid-stride the rest
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(lik_bt_kernel, dim3((unsigned)grid), dim3(LIK_BLOCK), 0, s, bt, n_items, th,
-                       reinterpret_cast<const LogTab *>(ctx->log_tab), lM, p_Bt_g_Ft);
-    FCD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lik_b_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, b, C, (int)H, th, S_B,
-                       lp_B_g_F);
+    const int64_t n_b_blocks = (C + 15) / 16;
+    fcd_prof_begin(ctx, FCD_PROF_LIK, s);
+    hipLaunchKernelGGL(lik_kernel, dim3((unsigned)(grid + n_b_blocks)), dim3(LIK_BLOCK), 0, s, bt, n_items, th,
+                       reinterpret_cast<const LogTab *>(ctx->log_tab), lM, p_Bt_g_Ft, (int)grid, b, C, (int)H, S_B, lp_B_g_F);
+    fcd_prof_end(ctx, FCD_PROF_LIK, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

@@ -66,6 +66,13 @@ int fcd_ctx_create(fcd_ctx **out);
 int fcd_ctx_destroy(fcd_ctx *ctx);
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 
+/* Optional timing of the library's main kernels with HIP events recorded on the launch stream, each pair
+ * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r panel, 3 r diagonal.
+ * fcd_prof_collect waits for the recorded events, returns the summed milliseconds and the number of
+ * launches, and clears the slot.  Off by default (no events are recorded). */
+int fcd_prof_enable(fcd_ctx *ctx, int on);
+int fcd_prof_collect(fcd_ctx *ctx, int slot, double *total_ms, int64_t *count);
+
 /* ---- index maps: fcdiff/util.py:7-84 (host, integer) ------------------------------------- */
 int64_t fcd_N_to_C(int64_t Nreg);
 /* Returns Nreg with C = Nreg(Nreg-1)/2, or FCD_ERR_SHAPE when C is not triangular (fit.py:62-65). */
