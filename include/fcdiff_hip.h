@@ -95,6 +95,14 @@ int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, int64_t C, i
                    const double *theta12_host, double *S_B, double *lM, double *lp_B_g_F,
                    double *p_Bt_g_Ft, fcd_stream stream);
 
+/* ---- front-end: region x time series -> edge-major correlations --------------------------------------
+ * Not in the reference (its inputs are already correlations, fit.py:20-23); oracle = numpy.corrcoef.
+ * ts (S, Nreg, T) -> out (C, S), out[c][s] = corrcoef(ts[s])[n, m] for c = n(n-1)/2 + m, n > m: the layout of
+ * b / bt.  fp64 MFMA Gram product per subject.  fisher_z != 0 applies atanh; keep it 0 with the reference's model
+ * defaults, which are calibrated on raw correlations clipped to [-1, 1] (fcdiff/model.py:213, 236). */
+int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t Nreg, int64_t T, int fisher_z, double *out,
+                   fcd_stream stream);
+
 /* ---- variational updates ------------------------------------------------------------------ */
 /* UnsharedRegionFit._update_lq_F, fit.py:157-174 (+ _eval_q_R_w 382-406). */
 int fcd_vb_update_qF(fcd_ctx *ctx, const double *lq_R, const double *S_B, const double *lM,

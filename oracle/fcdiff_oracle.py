@@ -585,3 +585,17 @@ def gibbs_logjoint(f, r, S_B, lM, lngamma, lnpi2):
         lj += np.sum(lM[cs[:, None], np.arange(lM.shape[1])[None, :], fg[:, None], l])
         out[g] = lj
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# front-end oracle (third party: numpy.corrcoef; no reference code exists -> "parity unpinned")
+# ----------------------------------------------------------------------------------------
+def corr_edges(ts, fisher_z=False):
+    """(S, Nreg, T) -> (C, S): numpy.corrcoef per subject, lower-triangular edge order (util.py:62-84)."""
+    (S, Nreg, _T) = ts.shape
+    ends = edge_endpoints(Nreg)
+    out = np.zeros((ends.shape[0], S))
+    for s in range(S):
+        cc = np.corrcoef(ts[s])
+        out[:, s] = cc[ends[:, 0], ends[:, 1]]
+    return np.arctanh(out) if fisher_z else out

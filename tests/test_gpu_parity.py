@@ -504,3 +504,95 @@ def test_gibbs_cfg3_size_properties(env):
         assert np.array_equal(f_g[c0:c0 + 4], f_o) and np.array_equal(r_g[c0:c0 + 4], r_o)
     lj = full.logjoint().cpu().numpy()
     nptest.assert_allclose(lj[:4], env.CO.gibbs_logjoint(f_g[:4].copy(), r_g[:4].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
+
+
+def test_gibbs_cfg2_full_size_against_oracle(env):
+    """BASELINE cfg 2 (Nreg=64, H=U=16, 256 chains): every chain, 2 sweeps, state for state against the C oracle."""
+    (N, H, U, G) = (64, 16, 16, 256)
+    (m, S_B, lM) = tables_for(env, N, H, U, seed=22)
+    seed = 64016
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, seed=seed, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.05)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.05, seed, 0)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for s in range(2):
+        eng.sweeps(s, 1)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, 1, 0)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
+def test_gibbs_cfg5_shape_properties(env):
+    """
+    BASELINE cfg 5 shape (Nreg=400, C=79 800, H=U=250) with 128 chains: U > 64 takes the scalar-mask f kernel, the
+    r pass walks 25 blocks of 16 regions.  First chains equal the C oracle, a shard equals its slice, counts recount.
+    """
+    (N, H, U, G) = (400, 250, 250, 128)
+    m = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=55)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    S_B_d, lM_d = fit._d["S_B"], fit._d["lM"]
+    seed = 555
+
+    def run(c0, g):
+        eng = env.GibbsEngine(S_B_d, lM_d, N, U, g, chain0=c0, seed=seed, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.05)
+        eng.sweeps(0, 1)
+        return eng
+    full = run(0, G)
+    f_g, r_g = full.export_state()
+    shard = run(64, 64).export_state()
+    assert np.array_equal(f_g[64:], shard[0]) and np.array_equal(r_g[64:], shard[1])
+    c = full.stats().cpu().numpy()
+    assert c[0] == r_g.sum(dtype=np.int64) and [c[1], c[2], c[3]] == [(f_g == k).sum() for k in range(3)]
+    S_B, lM = S_B_d.cpu().numpy(), lM_d.cpu().numpy()
+    S_Bo, lMo = env.CO.lik_tables(b, bt, m.theta())
+    nptest.assert_allclose(lM, lMo, **TAB)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    f_o, r_o = env.CO.gibbs_init(2, N, U, 0.05, seed, 0)
+    env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, 0, 0)
+    env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, 0, 1, 0)
+    assert np.array_equal(f_g[:2], f_o) and np.array_equal(r_g[:2], r_o)
+
+
+@pytest.mark.parametrize("S,N,T", [(3, 10, 200), (2, 37, 53), (5, 64, 400), (1, 2, 2), (2, 17, 1201)])
+def test_corr_front_end_against_numpy(env, S, N, T):
+    """K_corr (fp64 MFMA Gram) vs numpy.corrcoef; oracle is third-party (not in the reference): parity unpinned."""
+    from fcdiff_amd.corr import correlations
+    rs = np.random.RandomState(S * 1000 + N)
+    base = rs.standard_normal((S, 1, T))
+    ts = rs.standard_normal((S, N, T)) + 0.7 * base          # correlated regions
+    ts[:, 0, :] *= 1e3                                        # scale invariance
+    if N > 3:
+        ts[:, 3, :] = -2.0 * ts[:, 1, :] + 5.0               # exactly anti-correlated pair -> clipped to -1
+    got = correlations(ts, ctx=env.ctx)
+    exp = env.O.corr_edges(ts)
+    assert got.shape == (N * (N - 1) // 2, S)
+    nptest.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+    assert got.min() >= -1.0 and got.max() <= 1.0
+    if N > 3 and T > 2:
+        z = correlations(ts[:, [0, 2]], fisher_z=True, ctx=env.ctx)
+        nptest.assert_allclose(z, env.O.corr_edges(ts[:, [0, 2]], fisher_z=True), rtol=1e-10, atol=1e-13)
+
+
+def test_corr_feeds_the_fitter(env):
+    """time series -> correlations -> variational fit: the edge order of K_corr is the fitter's."""
+    from fcdiff_amd.corr import correlations
+    (S, N, T) = (8, 12, 300)
+    rs = np.random.RandomState(1)
+    ts = rs.standard_normal((S, N, T))
+    out = correlations(ts, ctx=env.ctx)
+    fit = new_fit(env)
+    fit.model = env.pkg.UnsharedRegionModel()
+    fit.model.sigma = np.array([0.1, 0.1, 0.1])
+    fit.b, fit.bt = out[:, :4].copy(), out[:, 4:].copy()
+    fit.max_iters = 2
+    fit.run()
+    assert len(fit.energy) >= 2 and np.all(np.isfinite(fit.energy))
