@@ -266,19 +266,30 @@ __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__rest
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging
+    // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
+    // Consecutive edges c = n(n-1)/2 + m share n: its words are fetched once per run, not once per edge.
     uint32_t X[FP_EC][NW32], A[FP_EC][NW32];
     if (w < GW) {
         const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW32 * 64 + lane;
+        int n, m;
+        fcd_edge_to_pair(c0, n, m);
+        uint32_t rn[NW32];
+#pragma unroll
+        for (int j = 0; j < NW32; ++j) rn[j] = ru[(int64_t)(n * NW32 + j) * 64];
 #pragma unroll
         for (int e = 0; e < FP_EC; ++e) {
-            int n, m;
-            fcd_edge_to_pair(c0 + (e < ne ? e : 0), n, m);
 #pragma unroll
             for (int j = 0; j < NW32; ++j) {
-                const uint32_t rn = ru[(int64_t)(n * NW32 + j) * 64], rm = ru[(int64_t)(m * NW32 + j) * 64];
-                X[e][j] = rn ^ rm;
-                A[e][j] = rn & rm;
+                const uint32_t rm = ru[(int64_t)(m * NW32 + j) * 64];
+                X[e][j] = rn[j] ^ rm;
+                A[e][j] = rn[j] & rm;
+            }
+            // next edge of the lower-triangular order: (n, m+1), or (n+1, 0) at the end of row n
+            if (++m == n) {
+                m = 0;
+                n = (n + 1 < Nreg) ? n + 1 : n;       // past the last edge only for e >= ne (unused)
+#pragma unroll
+                for (int j = 0; j < NW32; ++j) rn[j] = ru[(int64_t)(n * NW32 + j) * 64];
             }
         }
     }

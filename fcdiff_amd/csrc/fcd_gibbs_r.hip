@@ -78,11 +78,25 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
     f_r[(int64_t)item * 64 + lane] = v;
 }
 
+__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
+                                uint32_t k0, uint32_t k1, int lane);
+
+// items [0, GW*U*NBLK): r words; items beyond: the thresholds of block 0 (one wave per (w, u, pair of regions))
 __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
-                                                     uint16_t *__restrict__ r_T) {
+                                                     uint16_t *__restrict__ r_T, double *__restrict__ thr0, uint32_t chain0,
+                                                     uint64_t seed, uint32_t sweep) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= GW * U * NBLK) return;
+    const int n_pack = GW * U * NBLK;
+    if (item >= n_pack) {
+        const int it = item - n_pack;                 // (w, u, p): p = pair of regions of block 0
+        if (it >= GW * U * (R_NB / 2)) return;
+        const int p = it % (R_NB / 2), wu = it / (R_NB / 2);
+        const int u = wu % U, w = wu / U;
+        thr_pair(thr0 + ((int64_t)wu * R_NB) * 64, 0, p, U, u, chain0 + (uint32_t)w * 64u + lane, sweep, (uint32_t)seed,
+                 (uint32_t)(seed >> 32), lane);
+        return;
+    }
     const int b = item % NBLK, u = (item / NBLK) % U, w = item / (NBLK * U);
     uint32_t v = 0;
 #pragma unroll
@@ -228,15 +242,6 @@ __device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int 
     const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
     thr_wu[(2 * p) * 64 + lane] = fcd_logit(fcd_u53(x.x, x.y));
     thr_wu[(2 * p + 1) * 64 + lane] = fcd_logit(fcd_u53(x.z, x.w));
-}
-
-__global__ __launch_bounds__(256) void r_thr0_kernel(double *__restrict__ thr, int U, uint32_t chain0, uint64_t seed,
-                                                     uint32_t sweep) {
-    const int u = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    double *thr_wu = thr + (((int64_t)w * U + u) * R_NB) * 64;
-    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-    thr_pair(thr_wu, 0, 2 * q, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
-    thr_pair(thr_wu, 0, 2 * q + 1, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
 }
 
 // f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
@@ -528,11 +533,9 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
         hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
                            (int)g.C, edge_mode, f_r);
         FCD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
-                           g.GW, r_T);
-        FCD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(r_thr0_kernel, dim3((unsigned)U, (unsigned)g.GW), dim3(256), 0, s, thr[0], (int)U, (uint32_t)chain0,
-                           seed, (uint32_t)sweep);
+        const int64_t items_t = (int64_t)g.GW * U * (R_NB / 2);       // + thresholds of block 0
+        hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + items_t + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg,
+                           (int)U, NBLK, g.GW, r_T, thr[0], (uint32_t)chain0, seed, (uint32_t)sweep);
         FCD_LAUNCH_CHECK();
     }
     fcd_abl_refresh(s);

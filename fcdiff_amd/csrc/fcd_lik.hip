@@ -13,6 +13,7 @@ namespace {
 struct LikTheta {
     double mu[3];
     double sigma[3];
+    double inv_sigma[3];   // 1 / sigma_k
     double pdf_scale[3];   // 1 / sqrt(2 pi) / sigma_k  (the reference's two divisions applied to 1.0)
     double lnsigma[3];
     double eps[3];       // _eval_M_eps(eta, epsilon, l), l = 0,1,2
@@ -132,16 +133,18 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict
             double N[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                // scipy.stats.norm.pdf: exp(-z*z/2) / sqrt(2 pi) / sigma   (fit.py:115).  z keeps the reference's
-                // division (the exponent decides WHERE the density underflows to 0, i.e. where lM = -inf, and that
-                // pattern must match); the two divisions of the result are one multiplication by a host-side
-                // 1/sqrt(2 pi)/sigma (<= 1 ulp of the density): the kernel is ALU-bound, fp64 division ~15 instructions.
-                const double z = (x - th.mu[k]) / th.sigma[k];
-                const double e = exp(-(z * z) / 2.0);
-                N[k] = e * th.pdf_scale[k];
-                // at the edge of the double range the reference's two roundings decide whether the density is 0
-                // (lM = -inf) or a subnormal: redo exactly its operations there (rare, wave-divergent only then)
-                if (N[k] < 1e-290) N[k] = e / kSqrt2Pi / th.sigma[k];
+                // scipy.stats.norm.pdf: exp(-z*z/2) / sqrt(2 pi) / sigma   (fit.py:115).  The kernel is ALU-bound and
+                // an fp64 division is ~15 instructions, so the three divisions per component are multiplications by
+                // host-side reciprocals (<= 2 ulp of the density, ~1e-16 relative in log M) ...
+                const double d = x - th.mu[k];
+                const double z = d * th.inv_sigma[k];
+                N[k] = exp(-(z * z) / 2.0) * th.pdf_scale[k];
+                // ... except at the edge of the double range, where the reference's own roundings decide whether the
+                // density is 0 (lM = -inf) or a subnormal: there its operations are redone exactly (rare branch)
+                if (N[k] < 1e-290) {
+                    const double ze = d / th.sigma[k];
+                    N[k] = exp(-(ze * ze) / 2.0) / kSqrt2Pi / th.sigma[k];
+                }
             }
             if (pBt) {
                 pBt[i * 3 + 0] = N[0];
@@ -187,6 +190,7 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     for (int k = 0; k < 3; ++k) {
         th.mu[k] = theta[6 + k];
         th.sigma[k] = theta[9 + k];
+        th.inv_sigma[k] = 1.0 / theta[9 + k];
         th.pdf_scale[k] = 1.0 / kSqrt2Pi / theta[9 + k];
         th.lnsigma[k] = log(theta[9 + k]);
     }
@@ -201,8 +205,8 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_items = C * U;
     const int64_t n_tiles = (n_items + LIK_BLOCK - 1) / LIK_BLOCK;
-    int64_t grid = n_tiles;
-    const int64_t cap = (int64_t)ctx->num_cu * 8;  // 8 blocks of 256 threads per CU, grid-stride the rest
+    int64_t grid = n_tiles;                          // one tile per block up to 16 blocks per CU, grid-stride beyond
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
     if (grid > cap) grid = cap;
     const int64_t n_b_blocks = (C + 15) / 16;
     fcd_prof_begin(ctx, FCD_PROF_LIK, s);
