@@ -14,6 +14,7 @@ New knobs (all optional; defaults reproduce the reference):
     edge_index   'reference' (fit.py:185-186 calls nm_to_c for every ordered pair: quirk Q1) |
                  'symmetric' (doc/methods.rst:646-653).  Default: 'reference' for vb, 'symmetric' for gibbs.
     n_chains, n_sweeps, burn_in, mstep_every, seed, chain0     sampler controls
+    update_theta_sub, theta_sub_every                          (eta, epsilon) step: vb every iteration / gibbs every K sweeps
 
 Differences from the reference that are deliberate and documented:
   Q4  `model.pi` may be the scalar the model defines or the 2-vector [1-pi, pi] the reference's updates
@@ -21,8 +22,9 @@ Differences from the reference that are deliberate and documented (SURVEY.md sec
   Q5  tables are float64 (the reference's np.full(shape, 1) buffers turn int64 on modern NumPy).
   Q7  run() is the documented loop (doc/methods.rst:564-600); `energy` is appended to.  The reference's
       run() raises IndexError on its first energy assignment (fit.py:73-74).  The (eta, epsilon)
-      optimiser step (fit.py:222-241) cannot run in the reference (calls undefined names) and is not
-      part of this round (`update_theta_sub` stays False).
+      optimiser step (fit.py:222-241) cannot run in the reference (it calls undefined names); here it is
+      implemented (`_update_theta_sub`, analytic gradient on the device) but stays OFF by default
+      (`update_theta_sub = False`) so that the default trajectory is the one the fixtures pin.
 """
 import numpy as np
 
@@ -59,6 +61,7 @@ class UnsharedRegionFit(object):
         self.n_sweeps = 100
         self.burn_in = 20
         self.mstep_every = 1
+        self.theta_sub_every = 0   # gibbs: re-fit (eta, epsilon) from pooled chain counts every this many sweeps (0: never)
         self.energy_every = 0
         self.seed = 0
         self.chain0 = 0
@@ -330,9 +333,27 @@ class UnsharedRegionFit(object):
         self.model.gamma = self._theta_step()[1:4].copy()
 
     def _update_theta_sub(self):
-        raise NotImplementedError(
-            "the (eta, epsilon) optimiser step cannot run in the reference (fit.py:239 calls the undefined "
-            "self.opt_fun) and is scheduled after the hot path (SURVEY.md section 8f item 1)")
+        """
+        Updates (eta, epsilon) (fit.py:222-241): bounded minimisation of -E_lM with the other terms fixed, bounds
+        (1e-5, 1 - 1e-5) on both, L-BFGS-B.  The reference's version cannot run (it calls the undefined `opt_fun`,
+        fit.py:239) and would difference the objective numerically (`jac=False`); here objective AND its two analytic
+        derivatives (the formulas of `_eval_dE_dh` / `_eval_dE_de`, fit.py:600-697) come from one kernel pass over bt.
+        mu and sigma stay fixed, as in the reference (commented out of its optimiser, fit.py:232-237, 250-251).
+        """
+        W = self._theta_sub_weights()
+        (eta, epsilon, info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model)
+        self.model.eta, self.model.epsilon = eta, epsilon
+        self._theta_sub_info = info
+
+    def _theta_sub_weights(self):
+        """W[c,u,k,l] = q_F[c,k] * w_l(c,u) on the device (fit.py:382-406, 508-510)."""
+        t = self._torch()
+        lq_R, lq_F = self._d["lq_R"], self._d["lq_F"]
+        (N, U) = (int(lq_R.shape[0]), int(lq_R.shape[1]))
+        W = t.empty((util.N_to_C(N), U, 3, 3), dtype=t.float64, device=self._dev())
+        self._context().call("fcd_theta_sub_weights_vb", _lib.dptr(lq_F), _lib.dptr(lq_R), N, U, _lib.dptr(W),
+                             _lib.stream_ptr())
+        return W
 
     # ------------------------------------------------------------------ gibbs
     def _run_gibbs(self, N, U):
@@ -353,6 +374,14 @@ class UnsharedRegionFit(object):
         def record(i, e):
             if self.energy_every and (i + 1) % self.energy_every == 0:
                 self.energy.append(-float(e.logjoint().mean()))
+            if self.update_theta_sub and self.theta_sub_every and (i + 1) % self.theta_sub_every == 0 and i + 1 < self.n_sweeps:
+                # Monte-Carlo EM for (eta, epsilon): pooled counts of (f_c, mixture case) over all chains of all ranks
+                W = e.pair_counts()
+                (eta, epsilon, _info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model,
+                                                           reduce=allreduce_counts)
+                self.model.eta, self.model.epsilon = eta, epsilon
+                self._update_lps()            # tables follow theta_sub ...
+                e.refresh_tables()            # ... and so do the sampler's two difference tables
         run_chains(eng, self.n_sweeps, sweep0=0, mstep_every=self.mstep_every, burn_in=self.burn_in,
                    update_theta=True, on_sweep=record)
         self.sampler = eng
@@ -369,6 +398,40 @@ class UnsharedRegionFit(object):
         (gamma, pi) = eng.hyper_values()
         self.model.gamma = gamma
         self.model.pi = pi
+
+
+def theta_sub_objective(ctx, bt_dev, W, theta, reduce=None):
+    """
+    (S, dS/d eta, dS/d epsilon), S = sum W ln M(bt; eta, epsilon), through fcd_theta_sub_objective.
+    `reduce` (optional) sums the three numbers over ranks (multi-GPU sampler: W holds this rank's chain counts).
+    """
+    import torch
+    out = torch.empty(3, dtype=torch.float64, device=W.device)
+    (th, _th) = _lib.dbl_array(theta)
+    ctx.call("fcd_theta_sub_objective", _lib.dptr(bt_dev), _lib.dptr(W), int(W.shape[0]), int(W.shape[1]), th,
+             _lib.dptr(out), _lib.stream_ptr())
+    if reduce is not None:
+        out = reduce(out)
+    return out.cpu().numpy()
+
+
+def minimize_theta_sub(ctx, bt_dev, W, model, reduce=None, bound_eps=1e-5):
+    """
+    argmin over (eta, epsilon) in [1e-5, 1-1e-5]^2 of -sum W ln M (fit.py:222-241), analytic gradient, L-BFGS-B.
+    Returns (eta, epsilon, scipy result).  The model is not modified.
+    """
+    import scipy.optimize as spopt
+    base = np.array(model.theta(), dtype=np.float64)
+
+    def fun(x):
+        th = base.copy()
+        th[1], th[2] = float(x[0]), float(x[1])
+        (S, dh, de) = theta_sub_objective(ctx, bt_dev, W, th, reduce)
+        return (-S, np.array([-dh, -de]))
+    bnds = ((bound_eps, 1 - bound_eps), (bound_eps, 1 - bound_eps))          # fit.py:228-231
+    x0 = np.clip(np.array([model.eta, model.epsilon], dtype=np.float64), bound_eps, 1 - bound_eps)
+    res = spopt.minimize(fun, x0, jac=True, bounds=bnds, method="L-BFGS-B")
+    return float(res.x[0]), float(res.x[1]), res
 
 
 # ---------------------------------------------------------------------------------------------------------

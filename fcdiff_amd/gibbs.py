@@ -165,6 +165,16 @@ class GibbsEngine(object):
             self.n_accumulated += 1
         return self.counts if want_counts else None
 
+    def pair_counts(self, out=None, accumulate=False):
+        """(C, U, 3, 3) float64: number of this rank's chains with f_c = k and mixture case l at (c, u)."""
+        t = self.torch
+        if out is None:
+            out = t.empty((self.C, self.U, 3, 3), dtype=t.float64, device=self.f_state.device)
+            accumulate = False
+        self.ctx.call("fcd_gibbs_pair_counts", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      1 if accumulate else 0, _lib.dptr(out), _lib.stream_ptr())
+        return out
+
     # ---- diagnostics ----
     def logjoint(self):
         out = self.torch.empty(self.G, dtype=self.torch.float64, device=self.f_state.device)

@@ -121,6 +121,21 @@ int fcd_vb_energy(fcd_ctx *ctx, const double *lq_F, const double *lq_R, const do
 int fcd_vb_theta_step(fcd_ctx *ctx, const double *lq_F, const double *lq_R, int64_t Nreg, int64_t U,
                       double *out4, double *hyper, fcd_stream stream);
 
+/* ---- (eta, epsilon) step: objective and analytic gradient --------------------------------------------
+ * The reference sketches a bounded minimisation of -E_lM over (eta, epsilon) (fit.py:222-286) that cannot run there
+ * (fit.py:239 calls an undefined name); its derivative helpers are complete (fit.py:600-697).  For weights
+ * W (C, U, 3, 3) >= 0 these return out3 = {S, dS/d eta, dS/d epsilon} (device), S = sum W[c,u,k,l] ln M_kl(bt_cu):
+ *   W = q_F[c,k] w_l(c,u)            -> S = E_lM (fit.py:489-511), energy derivative = -dS  (variational fit)
+ *   W = pooled chain counts          -> Monte-Carlo EM objective of the sampler
+ * theta12_host as in fcd_lik_tables.  Deterministic. */
+int fcd_theta_sub_weights_vb(fcd_ctx *ctx, const double *lq_F, const double *lq_R, int64_t Nreg, int64_t U, double *W,
+                             fcd_stream stream);
+/* W[c,u,k,l] (+)= number of this rank's chains with f_c = k and mixture case l at (c,u)  (accumulate != 0: add). */
+int fcd_gibbs_pair_counts(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
+                          int64_t G, int accumulate, double *W, fcd_stream stream);
+int fcd_theta_sub_objective(fcd_ctx *ctx, const double *bt, const double *W, int64_t C, int64_t U,
+                            const double *theta12_host, double *out3, fcd_stream stream);
+
 /* ---- many-chain collapsed Gibbs sampler ---------------------------------------------------
  * Build-defined (the reference ships only the variational fitter, doc/methods.rst:236-239).  Its two
  * conditionals are the reference's updates at one-hot q:

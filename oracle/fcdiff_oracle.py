@@ -599,3 +599,51 @@ def corr_edges(ts, fisher_z=False):
         cc = np.corrcoef(ts[s])
         out[:, s] = cc[ends[:, 0], ends[:, 1]]
     return np.arctanh(out) if fisher_z else out
+
+
+# ----------------------------------------------------------------------------------------
+# (eta, epsilon) step: objective and gradient for general weights W (C,U,3,3)
+#   W = q_F[c,k] * w_l(c,u)  ->  (E_lM, -dE/dh, -dE/de) of fit.py:489-511, 600-664
+# ----------------------------------------------------------------------------------------
+def vb_weights(q_F, q_R):
+    C = q_F.shape[0]
+    U = q_R.shape[1]
+    W = np.zeros((C, U, 3, 3))
+    for c in range(C):
+        (n, m) = c_to_nm(c)
+        w = eval_q_R_w(q_R, n, m)
+        for k in range(3):
+            W[c, :, k, :] = q_F[c, 0, k] * w
+    return W
+
+
+def theta_sub_objective(bt, W, mu, sigma, eta, epsilon):
+    (C, U) = bt.shape
+    norm = np.zeros((C, U, 3))
+    for k in range(3):
+        norm[:, :, k] = norm_pdf(bt, mu[k], sigma[k])
+    S = dh = de = 0.0
+    for k in range(3):
+        for l in range(3):
+            M = eval_M(norm, eta, epsilon, k, l)
+            w = W[:, :, k, l]
+            nz = w != 0
+            S += np.sum(w[nz] * np.log(M[nz]))
+            de += np.sum(w[nz] * eval_dlM_de(norm, M, eta, k, l)[nz])
+            if l == 2:
+                dh += np.sum(w[nz] * eval_dlM_dh(norm, M, epsilon, k)[nz])
+    return S, dh, de
+
+
+def pair_counts(f, r):
+    """(C,U,3,3) counts over chains of (f_c, mixture case at (c,u))."""
+    (G, C) = f.shape
+    (Nreg, U) = r.shape[1:]
+    ends = edge_endpoints(Nreg)
+    W = np.zeros((C, U, 3, 3))
+    cs = np.arange(C)[:, None]
+    us = np.arange(U)[None, :]
+    for g in range(G):
+        l = mix_index(r[g][ends[:, 0]], r[g][ends[:, 1]])
+        np.add.at(W, (cs, us, f[g].astype(np.int64)[:, None], l), 1.0)
+    return W

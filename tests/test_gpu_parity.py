@@ -597,3 +597,97 @@ def test_corr_feeds_the_fitter(env):
     fit.max_iters = 2
     fit.run()
     assert len(fit.energy) >= 2 and np.all(np.isfinite(fit.energy))
+
+
+# ------------------------------------------------------------------------------------------------
+# (eta, epsilon) step
+# ------------------------------------------------------------------------------------------------
+def test_theta_sub_objective_matches_reference_derivative_helpers(env):
+    """
+    Kernel objective / gradient with W = q_F w_l against the reference's own formulas: E_lM (fit.py:489-511),
+    _eval_dE_dh (600-615), _eval_dE_de (644-664) -- the oracle's restatements of those are pinned by fixture G8.
+    """
+    from fcdiff_amd.fit import theta_sub_objective
+    (N, H, U) = (9, 3, 7)
+    m = env.pkg.UnsharedRegionModel()
+    m.eta, m.epsilon = 0.29, 0.07
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=3)
+    C = N * (N - 1) // 2
+    rs = np.random.RandomState(5)
+    q_F = rs.uniform(1e-7, 1, (C, 1, 3))
+    q_F /= q_F.sum(axis=2, keepdims=True)
+    q_R = rs.uniform(1e-7, 1, (N, U, 2))
+    q_R /= q_R.sum(axis=2, keepdims=True)
+    fit = new_fit(env)
+    fit.model, fit.b, fit.bt = m, b, bt
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    fit._lq_F, fit._lq_R = np.log(q_F), np.log(q_R)
+    W = fit._theta_sub_weights()
+    nptest.assert_allclose(W.cpu().numpy(), env.O.vb_weights(q_F, q_R), rtol=1e-13)
+    (S, dh, de) = theta_sub_objective(env.ctx, fit._d["bt"], W, m.theta())
+    norm = np.stack([env.O.norm_pdf(bt, m.mu[k], m.sigma[k]) for k in range(3)], axis=2)
+    mix = np.stack([np.stack([env.O.eval_M(norm, m.eta, m.epsilon, k, l) for l in range(3)], axis=2) for k in range(3)], axis=2)
+    nptest.assert_allclose(S, env.O.eval_E_lM(q_F, q_R, np.log(mix)), rtol=1e-11)
+    nptest.assert_allclose(-dh, env.O.eval_dE_dh(q_R, q_F, norm, mix, m.epsilon), rtol=1e-10)
+    nptest.assert_allclose(-de, env.O.eval_dE_de(q_R, q_F, norm, mix, m.eta), rtol=1e-10)
+    # and the gradient is the derivative of the objective (central differences)
+    for (j, g) in ((1, dh), (2, de)):
+        h = 1e-6
+        (tp, tm) = (m.theta(), m.theta())
+        tp[j] += h
+        tm[j] -= h
+        fd = (theta_sub_objective(env.ctx, fit._d["bt"], W, tp)[0] - theta_sub_objective(env.ctx, fit._d["bt"], W, tm)[0]) / (2 * h)
+        nptest.assert_allclose(g, fd, rtol=1e-6)
+
+
+def test_pair_counts_and_mcem_theta_sub(env):
+    """Pooled (f, mixture case) counts equal a recount; the MCEM step moves (eta, epsilon) towards the planted values."""
+    (N, H, U, G) = (14, 6, 20, 96)
+    gen = env.pkg.UnsharedRegionModel()
+    gen.pi, gen.eta, gen.epsilon = 0.15, 0.6, 0.08
+    gen.gamma, gen.mu, gen.sigma = np.ones(3) / 3, np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (r, t, f, ft, b, bt) = gen.sample_fast(N, H, U, seed=9)
+    fit = new_fit(env)
+    fit.method, fit.b, fit.bt = "gibbs", b, bt
+    fit.model = make_model(env, gen.theta())
+    fit.model.eta, fit.model.epsilon = 0.3, 0.02                     # start away from the truth
+    fit.n_chains, fit.n_sweeps, fit.burn_in = G, 30, 10
+    fit.update_theta_sub, fit.theta_sub_every = True, 10
+    fit.run()
+    eng = fit.sampler
+    (f_g, r_g) = eng.export_state()
+    nptest.assert_array_equal(eng.pair_counts().cpu().numpy(), env.O.pair_counts(f_g, r_g))
+    assert abs(fit.model.eta - 0.6) < abs(0.3 - 0.6) and 1e-5 <= fit.model.eta <= 1 - 1e-5
+    assert abs(fit.model.epsilon - 0.08) < abs(0.02 - 0.08) + 0.02
+
+
+def test_vb_run_with_theta_sub(env):
+    """run() with the (eta, epsilon) step enabled: the free energy after the step is not above the one before it."""
+    (N, H, U) = (12, 6, 10)
+    gen = env.pkg.UnsharedRegionModel()
+    gen.pi, gen.eta, gen.epsilon = 0.15, 0.6, 0.08
+    gen.gamma, gen.mu, gen.sigma = np.ones(3) / 3, np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (r, t, f, ft, b, bt) = gen.sample_fast(N, H, U, seed=2)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.edge_index = b, bt, "symmetric"
+    fit.model = make_model(env, gen.theta())
+    fit.model.eta, fit.model.epsilon = 0.3, 0.02
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    fit._update_lq_F()
+    fit._update_lq_R()
+    e0 = fit._eval_energy()
+    fit._update_theta_sub()
+    assert fit._theta_sub_info.success or fit._theta_sub_info.status in (0, 1, 2)
+    fit._update_lps()
+    e1 = fit._eval_energy()
+    assert e1 <= e0 + 1e-9 * abs(e0)
+    assert 1e-5 <= fit.model.eta <= 1 - 1e-5 and 1e-5 <= fit.model.epsilon <= 1 - 1e-5
+    full = new_fit(env)
+    full.b, full.bt, full.edge_index, full.update_theta_sub = b, bt, "symmetric", True
+    full.model = make_model(env, gen.theta())
+    full.model.eta, full.model.epsilon = 0.3, 0.02
+    full.rel_tol, full.max_iters = -np.inf, 3
+    full.run()
+    assert len(full.energy) == 4 and np.all(np.isfinite(full.energy))
