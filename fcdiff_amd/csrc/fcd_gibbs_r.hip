@@ -394,6 +394,166 @@ __global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__res
 }
 
 // ---------------------------------------------------------------------------------------------
+// ROW-SEQUENTIAL r pass (alternative, FCD_R_PATH=1; same chains bit for bit): ONE launch walks all regions in order.
+//
+// grid = (U, ceil(GW / WB)); block = 16 waves = WB chain words x MS "splits" (WB = 16 / MS).  Wave (word, s) owns the
+// regions m = s, s+MS, s+2MS, ...: it keeps their r bits of its 64 chains in ONE register (bit j <-> m = s + MS j),
+// and per region n gets the f codes of its edges (n, m) as one packed word (f2, made by pack_f2_kernel).
+// Per region n (a step):
+//   all waves   sum their terms  lMd[u][n][m][f_c][r_m]  from the LDS row of n (staged one step ahead, double buffer),
+//               put the partial sums in LDS, and meet at ONE barrier;
+//   owner wave  (s = n mod MS, the one whose register holds r_n) then adds the MS partials, compares with the
+//               precomputed threshold logit(x) (r_thr_all_kernel), flips its own bit, and publishes the 64 chains'
+//               r_n as a ballot -- while the other waves are already in step n+1 (they never need r_n).
+// No partial-sum buffer in HBM, no diagonal kernels, 3 launches per pass instead of 28.
+// ---------------------------------------------------------------------------------------------
+template <int MS>
+__global__ __launch_bounds__(256) void pack_f2_kernel(const uint8_t *__restrict__ f_state, int Nreg, int GW, int C32, int mode,
+                                                      uint64_t *__restrict__ f2) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);       // (w, n, s)
+    if (item >= GW * Nreg * MS) return;
+    const int s = item % MS, n = (item / MS) % Nreg, w = item / (MS * Nreg);
+    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64 + lane;
+    uint64_t v = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const int m = s + MS * j;
+        if (m < Nreg && m != n) v |= (uint64_t)fw[(int64_t)fcd_pair_to_edge(n, m, mode) * 64] << (2 * j);
+    }
+    f2[(int64_t)item * 64 + lane] = v;
+}
+
+// thr[((w*U + u)*Nreg + n)][lane] for every region: one wave per (w, u, pair of regions)
+__global__ __launch_bounds__(256) void r_thr_all_kernel(double *__restrict__ thr, int Nreg, int U, int GW, uint32_t chain0,
+                                                        uint64_t seed, uint32_t sweep) {
+    const int lane = threadIdx.x & 63;
+    const int n_np = (Nreg + 1) / 2;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (int64_t)GW * U * n_np) return;
+    const int p = (int)(item % n_np);
+    const int64_t wu = item / n_np;
+    const int u = (int)(wu % U), w = (int)(wu / U);
+    const fcd_u4 x = fcd_philox((uint32_t)(p * U + u), chain0 + (uint32_t)w * 64u + lane, sweep, FCD_KIND_R, (uint32_t)seed,
+                                (uint32_t)(seed >> 32));
+    double *o = thr + (wu * Nreg + 2 * p) * 64 + lane;
+    o[0] = fcd_logit(fcd_u53(x.x, x.y));
+    if (2 * p + 1 < Nreg) o[64] = fcd_logit(fcd_u53(x.z, x.w));
+}
+
+template <int MS>
+__global__ __launch_bounds__(1024) void gibbs_r_seq_kernel(const double *__restrict__ lMd, const double *__restrict__ hyper,
+                                                           const uint64_t *__restrict__ f2, const double *__restrict__ thr,
+                                                           uint64_t *__restrict__ r_bits, int Nreg, int U, int GW) {
+    constexpr int WB = 16 / MS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int row_dbl = Nreg * 6;
+    double *rows = smem;                                   // [2][Nreg*6]
+    double *part = smem + 2 * row_dbl;                     // [2][WB][MS][64]
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int jw = wave / MS, s = wave % MS;
+    const int w = blockIdx.y * WB + jw;
+    const bool live = w < GW;
+    const int njs = (Nreg - s + MS - 1) / MS;              // regions owned by this split
+    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
+    uint64_t *__restrict__ rcol = r_bits + (int64_t)(live ? w : 0) * Nreg * U + u;
+
+    uint32_t rw = 0;                                       // bit j = r of region s + MS j for this lane's chain
+    if (live) {
+        for (int j = 0; j < njs; ++j) rw |= (uint32_t)((rcol[(int64_t)(s + MS * j) * U] >> lane) & 1ull) << j;
+    }
+    const int row_d2 = Nreg * 3;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(lMd + ((int64_t)u * Nreg + 0) * row_dbl);
+        double2 *dst = reinterpret_cast<double2 *>(rows);
+        for (int i = threadIdx.x; i < row_d2; i += blockDim.x) dst[i] = src[i];
+    }
+    const uint64_t *__restrict__ f2w = f2 + ((int64_t)(live ? w : 0) * Nreg * MS + s) * 64 + lane;   // + n*MS*64
+    const double *__restrict__ thw = thr + (wu * Nreg) * 64 + lane;                                   // + n*64
+    const double dpi = hyper[FCD_H_LNPI1] - hyper[FCD_H_LNPI0];
+    const bool t0 = (int)threadIdx.x < row_d2, t1 = (int)threadIdx.x + 1024 < row_d2;
+    auto row_src = [&](int n) { return reinterpret_cast<const double2 *>(lMd + ((int64_t)u * Nreg + n) * row_dbl); };
+
+    // Latency plan (a step is ~1 us, an L2/HBM round trip about as much): the row of region n+1 is written to LDS at
+    // step n from registers that were loaded at step n-2; f words are fetched four steps at a time one group ahead;
+    // the owner fetches its next threshold MS steps ahead.
+    double2 pa0 = make_double2(0.0, 0.0), pa1 = pa0, pb0 = pa0, pb1 = pa0;     // rows in flight: (even, odd) issue steps
+    if (Nreg > 1) { if (t0) pa0 = row_src(1)[threadIdx.x]; if (t1) pa1 = row_src(1)[threadIdx.x + 1024]; }
+    if (Nreg > 2) { if (t0) pb0 = row_src(2)[threadIdx.x]; if (t1) pb1 = row_src(2)[threadIdx.x + 1024]; }
+    uint64_t fq[4], fn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        fq[q] = (live && q < Nreg) ? f2w[(int64_t)q * MS * 64] : 0ull;
+        fn[q] = (live && 4 + q < Nreg) ? f2w[(int64_t)(4 + q) * MS * 64] : 0ull;
+    }
+    double tcur = (live && s < Nreg) ? thw[(int64_t)s * 64] : 0.0;      // threshold of this wave's first own region n = s
+    __syncthreads();
+
+    // one region; p0/p1 hold row n+1 (loaded two steps ago) and are re-armed with row n+3
+    auto step = [&](int n, double2 &p0, double2 &p1, uint64_t fcur) {
+        const int cur = n & 1;
+        // this wave's terms of row n:  m = s + MS j  ->  record at (s + MS j) * 48 bytes; f picks +16 k, r picks +8 t
+        const char *rb = reinterpret_cast<const char *>(rows + cur * row_dbl) + s * 48;
+        double d0 = 0.0, d1 = 0.0;
+        const uint32_t flo = (uint32_t)fcur, fhi = (uint32_t)(fcur >> 32);
+        auto off = [&](uint32_t fword, int jf, int jr) -> uint32_t {
+            return (((fword >> (2 * jf)) & 3u) << 4) | (((rw >> jr) & 1u) << 3);
+        };
+        int j = 0;
+        for (; j + 4 <= njs && j < 16; j += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = *reinterpret_cast<const double *>(rb + off(flo, j + q, j + q) + (uint32_t)((j + q) * MS * 48));
+                if (q & 1) d1 += v; else d0 += v;
+            }
+        }
+        for (; j < njs && j < 16; ++j) d0 += *reinterpret_cast<const double *>(rb + off(flo, j, j) + (uint32_t)(j * MS * 48));
+        for (; j < njs; ++j)        // regions 16.. of this split: codes in the high word
+            d1 += *reinterpret_cast<const double *>(rb + off(fhi, j - 16, j) + (uint32_t)(j * MS * 48));
+        part[((cur * WB + jw) * MS + s) * 64 + lane] = d0 + d1;
+        if (n + 1 < Nreg) {
+            double2 *dst = reinterpret_cast<double2 *>(rows + (cur ^ 1) * row_dbl);
+            if (t0) dst[threadIdx.x] = p0;
+            if (t1) dst[threadIdx.x + 1024] = p1;
+        }
+        if (n + 3 < Nreg) {
+            if (t0) p0 = row_src(n + 3)[threadIdx.x];
+            if (t1) p1 = row_src(n + 3)[threadIdx.x + 1024];
+        }
+        // Barrier for LDS only.  __syncthreads() carries a workgroup fence that also drains every global load and
+        // store in flight (vmcnt(0)) -- i.e. the prefetches above -- on each of the Nreg steps.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (live && (n % MS) == s) {
+            // owner of region n: all partial sums, the draw, its own bit, the 64 chains' r_n as one word
+            const double *pp = part + ((cur * WB + jw) * MS) * 64 + lane;
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < MS; ++q) sum += pp[q * 64];
+            const uint32_t t = tcur < (dpi + sum) ? 1u : 0u;
+            const int jn = n / MS;
+            rw = (rw & ~(1u << jn)) | (t << jn);
+            const uint64_t ball = __ballot(t);
+            if (lane == 0) rcol[(int64_t)n * U] = ball;
+            if (n + MS < Nreg) tcur = thw[(int64_t)(n + MS) * 64];
+        }
+    };
+
+    for (int n = 0; n < Nreg; n += 4) {
+        step(n, pa0, pa1, fq[0]);
+        if (n + 1 < Nreg) step(n + 1, pb0, pb1, fq[1]);
+        if (n + 2 < Nreg) step(n + 2, pa0, pa1, fq[2]);
+        if (n + 3 < Nreg) step(n + 3, pb0, pb1, fq[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fq[q] = fn[q];
+            fn[q] = (live && n + 8 + q < Nreg) ? f2w[(int64_t)(n + 8 + q) * MS * 64] : 0ull;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic fallback (no region-major table, or a row that does not fit the LDS): one block per
 // (patient, chain word), regions strictly in order, the four waves split the sum over m, direct gathers.
 // ---------------------------------------------------------------------------------------------
@@ -513,6 +673,49 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
                            r_bits, (int)Nreg, (int)U, g.C, (uint32_t)chain0, seed, (uint32_t)sweep, edge_mode);
         FCD_LAUNCH_CHECK();
         return FCD_OK;
+    }
+    // ---- row-sequential path: Nreg <= 32 regions per split with 8 or 16 splits, rows of <= 2048 double2 ----
+    {
+        // 0 (default): blocked panel/diagonal kernels; 1: row-sequential kernel.  Measured at cfg3: 0.59 ms vs 0.81 ms --
+        // the row-sequential form pays ~10 VALU instructions per term (the blocked panel ~2 per region, thanks to pair
+        // records and f/r words shared by the patients of a workgroup) and leaves CUs unevenly loaded (400 workgroups).
+        int path = 0;
+        if (const char *e = getenv("FCD_R_PATH")) path = atoi(e);
+        const int MSsel = (Nreg <= 256) ? 8 : 16;
+        const size_t seq_lds = ((size_t)2 * Nreg * 6 + (size_t)2 * 16 * 64) * sizeof(double);
+        if (path == 1 && Nreg <= 32 * MSsel && Nreg * 3 <= 2048 && seq_lds <= 64 * 1024 &&
+            (int64_t)g.GW * Nreg * MSsel < INT32_MAX / 4 && g.C * 64 <= INT32_MAX) {
+            const size_t f2_bytes = (size_t)g.GW * Nreg * MSsel * 64 * sizeof(uint64_t);
+            const size_t thr_bytes = (size_t)g.GW * U * Nreg * 64 * sizeof(double);
+            rc = fcd_ws_reserve(ctx, f2_bytes + thr_bytes + 512);
+            if (rc) return rc;
+            uint64_t *f2 = (uint64_t *)ctx->ws;
+            double *thr_all = (double *)((char *)ctx->ws + f2_bytes);
+            const int64_t items_f = (int64_t)g.GW * Nreg * MSsel;
+            if (MSsel == 8)
+                hipLaunchKernelGGL(pack_f2_kernel<8>, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, g.GW,
+                                   (int)g.C, edge_mode, f2);
+            else
+                hipLaunchKernelGGL(pack_f2_kernel<16>, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, g.GW,
+                                   (int)g.C, edge_mode, f2);
+            FCD_LAUNCH_CHECK();
+            const int64_t items_t = (int64_t)g.GW * U * ((Nreg + 1) / 2);
+            hipLaunchKernelGGL(r_thr_all_kernel, dim3((unsigned)((items_t + 3) / 4)), dim3(256), 0, s, thr_all, (int)Nreg, (int)U, g.GW,
+                               (uint32_t)chain0, seed, (uint32_t)sweep);
+            FCD_LAUNCH_CHECK();
+            const int WB = 16 / MSsel;
+            dim3 grid((unsigned)U, (unsigned)((g.GW + WB - 1) / WB));
+            fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
+            if (MSsel == 8)
+                hipLaunchKernelGGL(gibbs_r_seq_kernel<8>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
+                                   (int)U, g.GW);
+            else
+                hipLaunchKernelGGL(gibbs_r_seq_kernel<16>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
+                                   (int)U, g.GW);
+            fcd_prof_end(ctx, FCD_PROF_PANEL, s);
+            FCD_LAUNCH_CHECK();
+            return FCD_OK;
+        }
     }
     // blocked path.  Workspace: P | f_r | r_T
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);

@@ -390,6 +390,27 @@ def test_gibbs_conditionals_against_reference_pins(env, tag):
         nptest.assert_allclose(eng.logjoint().cpu().numpy(), np.full(G, g["logjoint_base"]), rtol=1e-12)
 
 
+@pytest.mark.parametrize("N,U,G,mode", [(10, 4, 64, "symmetric"), (35, 6, 130, "reference"), (200, 3, 64, "symmetric"),
+                                        (257, 2, 64, "symmetric")])
+def test_gibbs_row_sequential_r_pass(env, monkeypatch, N, U, G, mode):
+    """The alternative single-launch r pass (FCD_R_PATH=1; 8 or 16 splits of the regions) gives the oracle's chains too."""
+    monkeypatch.setenv("FCD_R_PATH", "1")
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    seed = 99 + N
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=4, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 4)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for s in range(2):
+        eng.sweeps(s, 1)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 4)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 4)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
 def test_gibbs_chain_sharding_invariance(env):
     """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
     (N, U, G) = (12, 6, 192)
