@@ -63,6 +63,8 @@ class UnsharedRegionFit(object):
         self.mstep_every = 1
         self.theta_sub_every = 0   # gibbs: re-fit (eta, epsilon) from pooled chain counts every this many sweeps (0: never)
         self.energy_every = 0
+        self.trace_every = 0       # gibbs: keep every chain's log-joint every this many sweeps in `trace` (chains, draws)
+        self.trace = None
         self.seed = 0
         self.chain0 = 0
         self.sampler = None       # the GibbsEngine of the last gibbs run
@@ -332,6 +334,13 @@ class UnsharedRegionFit(object):
             self._d["lq_R"] = t.full((N, 1, 2), -np.log(2), dtype=t.float64, device=self._dev())
         self.model.gamma = self._theta_step()[1:4].copy()
 
+    def diagnostics(self):
+        """split-R-hat / effective sample size of the per-chain log-joint trace of the last gibbs run (trace_every > 0)."""
+        from . import diagnostics as D
+        if self.trace is None or self.trace.shape[1] < 4:
+            raise ValueError("no trace: set trace_every > 0 and keep at least 4 recorded sweeps after burn_in")
+        return D.summary(self.trace)
+
     def _update_theta_sub(self):
         """
         Updates (eta, epsilon) (fit.py:222-241): bounded minimisation of -E_lM with the other terms fixed, bounds
@@ -371,9 +380,17 @@ class UnsharedRegionFit(object):
         eng.init(float(pi2[1]))
         self.energy = []
 
+        traces = []
+
         def record(i, e):
-            if self.energy_every and (i + 1) % self.energy_every == 0:
-                self.energy.append(-float(e.logjoint().mean()))
+            want_e = bool(self.energy_every and (i + 1) % self.energy_every == 0)
+            want_t = bool(self.trace_every and i >= self.burn_in and (i + 1) % self.trace_every == 0)
+            if want_e or want_t:
+                lj = e.logjoint()
+                if want_e:
+                    self.energy.append(-float(lj.mean()))
+                if want_t:
+                    traces.append(lj.cpu().numpy())
             if self.update_theta_sub and self.theta_sub_every and (i + 1) % self.theta_sub_every == 0 and i + 1 < self.n_sweeps:
                 # Monte-Carlo EM for (eta, epsilon): pooled counts of (f_c, mixture case) over all chains of all ranks
                 W = e.pair_counts()
@@ -385,6 +402,7 @@ class UnsharedRegionFit(object):
         run_chains(eng, self.n_sweeps, sweep0=0, mstep_every=self.mstep_every, burn_in=self.burn_in,
                    update_theta=True, on_sweep=record)
         self.sampler = eng
+        self.trace = np.stack(traces, axis=1) if traces else None
         # marginals pooled over this rank's chains and, when distributed, over all ranks
         cnt = t.cat([eng.cnt_f.reshape(-1).to(t.int64), eng.cnt_r.reshape(-1).to(t.int64),
                      t.tensor([eng.n_accumulated * eng.G], dtype=t.int64, device=eng.cnt_f.device)])

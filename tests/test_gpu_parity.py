@@ -476,8 +476,10 @@ def test_fit_gibbs_recovers_planted_structure(env):
     fit.method = "gibbs"
     fit.model = make_model(env, gen.theta())
     fit.b, fit.bt = b, bt
-    fit.n_chains, fit.n_sweeps, fit.burn_in, fit.energy_every = 128, 40, 10, 10
+    fit.n_chains, fit.n_sweeps, fit.burn_in, fit.energy_every, fit.trace_every = 128, 40, 10, 10, 2
     fit.run()
+    d = fit.diagnostics()                     # per-chain log-joint trace: 128 chains x 15 recorded sweeps
+    assert fit.trace.shape == (128, 15) and d["chains"] == 128 and np.isfinite(d["rhat"]) and d["ess"] > 10
     assert fit._lq_F.shape == (N * (N - 1) // 2, 1, 3) and fit._lq_R.shape == (N, U, 2)
     assert (np.argmax(fit._lq_F[:, 0, :], axis=1) == np.argmax(f, axis=1)).mean() > 0.98
     assert ((np.exp(fit._lq_R[:, :, 1]) > 0.5) == r).mean() > 0.9
