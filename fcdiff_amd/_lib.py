@@ -43,6 +43,7 @@ SIGNATURES = {
     "fcd_c_to_nm": (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "fcd_hyper_set": (_int, [_p, _p, C.POINTER(_dbl), C.POINTER(_dbl), _p]),
     "fcd_lik_tables": (_int, [_p, _p, _p, _i64, _i64, _i64, C.POINTER(_dbl), _p, _p, _p, _p, _p]),
+    "fcd_model_sample": (_int, [_p, C.POINTER(_dbl), _i64, _i64, _i64, _u64, _p, _p, _p, _p, _p, _p, _p]),
     "fcd_corr_edges": (_int, [_p, _p, _i64, _i64, _i64, _int, _p, _p]),
     "fcd_vb_update_qF": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p]),
     "fcd_vb_update_qR": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),

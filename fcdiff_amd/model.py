@@ -163,3 +163,30 @@ class UnsharedRegionModel(object):
         b = (mu[fk][:, None] + sg[fk][:, None] * g.standard_normal((C, H))).clip(-1, 1)
         b_tilde = (mu[ftk] + sg[ftk] * g.standard_normal((C, U))).clip(-1, 1)
         return (r, t, f, f_tilde, b, b_tilde)
+
+    def sample_gpu(self, N, H, U, seed=0, ctx=None):
+        """
+        `sample` on the GPU (counter RNG, every variable in parallel): same return types and distribution, the
+        fitter's edge order like `sample_fast`.  Needs the HIP library and a GPU (no fallback).
+        """
+        import ctypes as C
+        import torch
+        from . import _lib
+        ctx = ctx if ctx is not None else _lib.Context()
+        Ce = util.N_to_C(N)
+        dev = ctx.device
+        r = torch.empty((N, U), dtype=torch.uint8, device=dev)
+        t = torch.empty((Ce, U), dtype=torch.uint8, device=dev)
+        fk = torch.empty((Ce,), dtype=torch.uint8, device=dev)
+        ftk = torch.empty((Ce, U), dtype=torch.uint8, device=dev)
+        b = torch.empty((Ce, H), dtype=torch.float64, device=dev)
+        bt = torch.empty((Ce, U), dtype=torch.float64, device=dev)
+        (th, _th) = _lib.dbl_array(self.theta())
+        ctx.call("fcd_model_sample", th, N, H, U, C.c_uint64(int(seed)), _lib.dptr(r), _lib.dptr(t), _lib.dptr(fk),
+                 _lib.dptr(ftk), _lib.dptr(b), _lib.dptr(bt), _lib.stream_ptr())
+        fk, ftk = fk.cpu().numpy().astype(np.int64), ftk.cpu().numpy().astype(np.int64)
+        f = np.zeros((Ce, 3), dtype=bool)
+        f[np.arange(Ce), fk] = True
+        f_tilde = np.zeros((Ce, U, 3), dtype=bool)
+        np.put_along_axis(f_tilde, ftk[:, :, None], True, axis=2)
+        return (r.cpu().numpy() > 0, t.cpu().numpy() > 0, f, f_tilde, b.cpu().numpy(), bt.cpu().numpy())

@@ -95,6 +95,13 @@ int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, int64_t C, i
                    const double *theta12_host, double *S_B, double *lM, double *lp_B_g_F,
                    double *p_Bt_g_Ft, fcd_stream stream);
 
+/* ---- forward sampler: UnsharedRegionModel.sample, fcdiff/model.py:52-236, on the device ---------------
+ * Counter RNG (Philox), all variables drawn in parallel; the reference's MT19937 stream is not reproduced (the host
+ * sampler of the Python mirror does that) -- same distribution.  Type INDICES are returned: r (Nreg,U), t (C,U),
+ * f (C,), f_tilde (C,U) uint8; b (C,H), b_tilde (C,U) float64 clipped to [-1,1].  Edges in the fitter's order. */
+int fcd_model_sample(fcd_ctx *ctx, const double *theta12_host, int64_t Nreg, int64_t H, int64_t U, uint64_t seed, uint8_t *r,
+                     uint8_t *t, uint8_t *f, uint8_t *f_tilde, double *b, double *b_tilde, fcd_stream stream);
+
 /* ---- front-end: region x time series -> edge-major correlations --------------------------------------
  * Not in the reference (its inputs are already correlations, fit.py:20-23); oracle = numpy.corrcoef.
  * ts (S, Nreg, T) -> out (C, S), out[c][s] = corrcoef(ts[s])[n, m] for c = n(n-1)/2 + m, n > m: the layout of

@@ -714,3 +714,38 @@ def test_vb_run_with_theta_sub(env):
     full.rel_tol, full.max_iters = -np.inf, 3
     full.run()
     assert len(full.energy) == 4 and np.all(np.isfinite(full.energy))
+
+
+def test_model_sample_gpu_statistics(env):
+    """Device forward sampler: the statistical checks of test_fcdiff/test_model.py."""
+    m = env.pkg.UnsharedRegionModel()
+    m.pi, m.eta, m.epsilon = 0.3, 0.4, 0.2
+    m.gamma, m.mu, m.sigma = np.array([0.2, 0.5, 0.3]), np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (N, H, U) = (40, 6, 50)
+    (r, t, f, ft, b, bt) = m.sample_gpu(N, H, U, seed=1, ctx=env.ctx)
+    C = N * (N - 1) // 2
+    assert r.shape == (N, U) and r.dtype == bool and t.shape == (C, U) and f.shape == (C, 3) and ft.shape == (C, U, 3)
+    assert b.shape == (C, H) and bt.shape == (C, U) and b.dtype == np.float64
+    assert (f.sum(axis=1) == 1).all() and (ft.sum(axis=2) == 1).all() and np.abs(b).max() <= 1 and np.abs(bt).max() <= 1
+    nptest.assert_allclose(r.mean(), 0.3, atol=0.03)
+    nptest.assert_allclose(f.mean(axis=0), m.gamma, atol=0.05)
+    ends = np.array([env.pkg.c_to_nm(c) for c in range(C)])
+    rn, rm = r[ends[:, 0]], r[ends[:, 1]]
+    assert t[rn & rm].all() and not t[~rn & ~rm].any()
+    nptest.assert_allclose(t[rn ^ rm].mean(), 0.4, atol=0.03)
+    fk, ftk = np.argmax(f, axis=1), np.argmax(ft, axis=2)
+    same = ftk == fk[:, None]
+    nptest.assert_allclose(same[~t].mean(), 0.8, atol=0.02)
+    nptest.assert_allclose(same[t].mean(), 0.2, atol=0.03)
+    for k in range(3):
+        other = ftk[(fk == k)[:, None] & ~same]
+        counts = np.bincount(other, minlength=3)
+        assert counts[k] == 0 and abs(counts[(k + 1) % 3] / counts.sum() - 0.5) < 0.05       # the two others equally
+        nptest.assert_allclose(b[fk == k].mean(), m.mu[k], atol=0.02)
+        nptest.assert_allclose(b[fk == k].std(), m.sigma[k], atol=0.02)
+        nptest.assert_allclose(bt[ftk == k].mean(), m.mu[k], atol=0.02)
+        nptest.assert_allclose(bt[ftk == k].std(), m.sigma[k], atol=0.02)
+    again = m.sample_gpu(N, H, U, seed=1, ctx=env.ctx)
+    other_seed = m.sample_gpu(N, H, U, seed=2, ctx=env.ctx)
+    assert all(np.array_equal(a, c) for a, c in zip((r, t, f, ft, b, bt), again))
+    assert not np.array_equal(bt, other_seed[5])
