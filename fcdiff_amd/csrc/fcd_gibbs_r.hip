@@ -78,25 +78,11 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
     f_r[(int64_t)item * 64 + lane] = v;
 }
 
-__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
-                                uint32_t k0, uint32_t k1, int lane);
-
-// items [0, GW*U*NBLK): r words; items beyond: the thresholds of block 0 (one wave per (w, u, pair of regions))
 __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
-                                                     uint16_t *__restrict__ r_T, double *__restrict__ thr0, uint32_t chain0,
-                                                     uint64_t seed, uint32_t sweep) {
+                                                     uint16_t *__restrict__ r_T) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_pack = GW * U * NBLK;
-    if (item >= n_pack) {
-        const int it = item - n_pack;                 // (w, u, p): p = pair of regions of block 0
-        if (it >= GW * U * (R_NB / 2)) return;
-        const int p = it % (R_NB / 2), wu = it / (R_NB / 2);
-        const int u = wu % U, w = wu / U;
-        thr_pair(thr0 + ((int64_t)wu * R_NB) * 64, 0, p, U, u, chain0 + (uint32_t)w * 64u + lane, sweep, (uint32_t)seed,
-                 (uint32_t)(seed >> 32), lane);
-        return;
-    }
+    if (item >= GW * U * NBLK) return;
     const int b = item % NBLK, u = (item / NBLK) % U, w = item / (NBLK * U);
     uint32_t v = 0;
 #pragma unroll
@@ -108,49 +94,108 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// panel kernel.  grid = (regions of the block, patient chunks of UB, groups of chain words);
-// block = 64 * (chain words per group).
+// thresholds logit(x) of the counter RNG for one block of 16 regions: thr[((w*U + u)*R_NB + i)][lane].
+// r_nu = 1  <=>  thr < ln(pi/(1-pi)) + d.  They depend on (seed, chain, sweep, site) only, so they are made
+// ahead of the in-order part (role T of the step kernel).
+// ---------------------------------------------------------------------------------------------
+__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
+                                uint32_t k0, uint32_t k1, int lane) {
+    const int n = B0 + 2 * p;                    // B0 is even: both halves of a counter block belong to this tile
+    const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
+    thr_wu[(2 * p) * 64 + lane] = fcd_logit(fcd_u53(x.x, x.y));
+    thr_wu[(2 * p + 1) * 64 + lane] = fcd_logit(fcd_u53(x.z, x.w));
+}
+
+// f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
+__device__ inline uint32_t f_of(uint32_t word, int j) {
+    const uint32_t q = (word >> (4 * (j >> 1))) & 15u;
+    const uint32_t hi = (q * 11u) >> 5;          // q / 3 for q in 0..8
+    return (j & 1) ? q - 3u * hi : hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The block step kernel.  Launch s = 0 .. NBLK carries two kinds of independent work (role by blockIdx.x):
+//   D(s-1)  the in-order part of block s-1: for each (patient, chain word) walk its 16 regions, drawing r_n;
+//   P(s)    the panel sums of block s over every block EXCEPT s-1 and s: what P(s) reads (new r below block s-1,
+//           old r above block s) is final before D(s-1) starts, so the two run side by side; D(s) adds the terms
+//           against block s-1 (just redrawn) and against its own block itself.  P(s) also makes the thresholds
+//           (Philox + logit) of block s, consumed by D(s) in the next launch.
+// The few D workgroups come first in the grid and finish before the panel workgroups that start beside them, so a
+// launch lasts as long as its panel part -- the in-order part costs no time of its own.
+// Both roles use workgroups of (chain words per group) waves and the same LDS size; <= 64 VGPRs, two per CU.
 //
-// What limits this kernel is the number of wave-wide LDS reads (one per gathered value whatever the
-// number of distinct addresses: profiles/r01_ubench_lds_fp64.txt), so the tile holds PAIR records: for the
-// pair of regions (m, m+1) and patient u, all 9 x 4 sums
+// Role P: what limits it is the number of wave-wide LDS reads (one per gathered value whatever the number of
+// distinct addresses: profiles/r01_ubench_lds_fp64.txt), so the tile holds PAIR records: for the pair of regions
+// (m, m+1) and patient u, all 9 x 4 sums
 //   pr[q = 3k + k'][tt = t + 2t'] = lMd[u][n][m][k][t] + lMd[u][n][m+1][k'][t']              (288 bytes)
 // built in LDS from the two single rows while staging.  One 8-byte LDS read and one fp64 add then cover
 // TWO regions; the address is  q*32 + tt*8  from the packed f / r words (2 integer ops per term + 2 per pair).
-// LDS: singles [UB][Nreg*6] doubles (scratch) + pairs [8*NBLK][UB][36] doubles.
+// LDS: pairs [8*NBLK][UB][36] doubles + singles [UB][Nreg*6] doubles (scratch).
 // ---------------------------------------------------------------------------------------------
+struct r_step_args {
+    const double *lMd, *hyper;
+    const uint32_t *f_r;
+    uint16_t *r_T;
+    uint64_t *r_bits;
+    double *P_w;            // panel sums written by P(s)
+    const double *P_r;      // panel sums of block s-1 read by D(s-1)
+    double *thr_w;          // thresholds written by T(s)
+    const double *thr_r;    // thresholds of block s-1
+    int Nreg, U, NBLK, GW;
+    int wpb, nWG;           // chain words per workgroup, groups of chain words
+    int s, nD, nP;          // step and the number of workgroups per role
+    uint32_t chain0, sweep;
+    uint64_t seed;
+};
+
 constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
+// role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 36 entries <= 1024 threads
+constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
+constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
+
 template <int UB>
-__global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__ lMd, const uint32_t *__restrict__ f_r,
-                                                      const uint16_t *__restrict__ r_T, double *__restrict__ P, int Nreg,
-                                                      int U, int NBLK, int GW, int sb0, int sb1, int prow) {
-    // One launch serves a SUPERBLOCK: the blocks sb0 .. sb1-1 of 16 regions.  grid.x = its regions; all its blocks
-    // are left out of the sums (gibbs_r_diag adds them, in order).  P[((w*U + u)*prow + i)][lane], i = n - 16 sb0.
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, double *smem) {
+    const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
+    const int x0 = a.s > 0 ? a.s - 1 : 0, x1 = a.s + 1;       // blocks left out of the sums
+    const int rows = (Nreg - a.s * R_NB < R_NB) ? (Nreg - a.s * R_NB) : R_NB;
+    const int nUC = (U + UB - 1) / UB;
+    const int row = item % rows, uc = (item / rows) % nUC, wg = item / (rows * nUC);
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
     double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][Nreg*6]
-    const int n = sb0 * R_NB + blockIdx.x;
-    const int u0 = blockIdx.y * UB;
+    const int n = a.s * R_NB + row;
+    const int u0 = uc * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
+    if (FCD_ABL(1, 5)) return;            // ablation: empty role
     {
         const int row_d2 = Nreg * 3;
         double2 *dst = reinterpret_cast<double2 *>(single);
         for (int it = threadIdx.x; it < UB * row_d2; it += blockDim.x) {
             const int u = it / row_d2, i = it - u * row_d2;
             const int us = u < nu ? u : nu - 1;            // tail chunk: replicate the last patient (never stored)
-            dst[it] = reinterpret_cast<const double2 *>(lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i];
+            dst[it] = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i];
         }
     }
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const bool live = w < GW;
-    const uint32_t *__restrict__ fr = f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64 + lane;
+    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
+    const bool live = w < a.GW;
+    // Thresholds of this block (Philox + logit, consumed by D(s) in the next launch): one (patient, pair of regions)
+    // item per workgroup -- each wave its own chain word -- while the rows above are on their way from memory.
+    if (live && !FCD_ABL(2, 1)) {
+        const int n_items = U * (R_NB / 2);
+        for (int it = row + rows * uc; it < n_items; it += rows * nUC) {
+            const int p = it % (R_NB / 2), ut = it / (R_NB / 2);
+            if (a.s * R_NB + 2 * p < Nreg)
+                thr_pair(a.thr_w + (((int64_t)w * U + ut) * R_NB) * 64, a.s * R_NB, p, U, ut, a.chain0 + (uint32_t)w * 64u + lane,
+                         a.sweep, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), lane);
+        }
+    }
+    const uint32_t *__restrict__ fr = a.f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64 + lane;
     const uint16_t *__restrict__ rt[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         const int uu = u < nu ? u : nu - 1;
-        rt[u] = r_T + ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64 + lane;
+        rt[u] = a.r_T + ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64 + lane;
     }
     // state words of the first group of blocks: issued before the barriers, their latency hides behind the staging
     uint32_t fpv[P_GRP], rwv[P_GRP][UB];
@@ -162,6 +207,7 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
         for (int u = 0; u < UB; ++u) rwv[g][u] = (uint32_t)rt[u][b * 64] << 3;   // tt*8 sits at bits 3..4 after >> 2p
     }
     __syncthreads();
+    if (FCD_ABL(1, 4)) return;            // ablation: single rows staged, no pair records
     {
         // pair records: each thread keeps one of the 36 (q, tt) entries and walks the (pair, patient) list
         const int e = threadIdx.x % 36, step = blockDim.x / 36;
@@ -203,7 +249,7 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
             const int b = bg + g;
-            if (b >= NBLK || (b >= sb0 && b < sb1)) continue;
+            if (b >= NBLK || (b >= x0 && b < x1)) continue;
             if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g] + rwv[g][0] + rwv[g][UB - 1]); continue; }   // ablation: loads only
             const uint32_t fp = fpv[g];
             const uint32_t base = (uint32_t)b * ((R_NB / 2) * REC);
@@ -213,8 +259,8 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
                 const uint32_t qb = (((fp >> (4 * p)) & 15u) << 5) + (base + (uint32_t)p * REC);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const uint32_t a = ((rwv[g][u] >> (2 * p)) & 24u) | qb;
-                    d[u] += *reinterpret_cast<const double *>(pb + a + (uint32_t)u * 288u);
+                    const uint32_t ad = ((rwv[g][u] >> (2 * p)) & 24u) | qb;
+                    d[u] += *reinterpret_cast<const double *>(pb + ad + (uint32_t)u * 288u);
                 }
             }
         }
@@ -225,172 +271,159 @@ __global__ __launch_bounds__(1024) void gibbs_r_panel(const double *__restrict__
             for (int u = 0; u < UB; ++u) rwv[g][u] = rwn[g][u];
         }
     }
-    const int i = n - sb0 * R_NB;
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-        if (u < nu) P[(((int64_t)w * U + u0 + u) * prow + i) * 64 + lane] = d[u];
+        if (u < nu) a.P_w[(((int64_t)w * U + u0 + u) * R_NB + row) * 64 + lane] = d[u];
 }
 
-// ---------------------------------------------------------------------------------------------
-// thresholds logit(x) of the counter RNG for one block of 16 regions: thr[((w*U + u)*R_NB + i)][lane].
-// r_nu = 1  <=>  thr < ln(pi/(1-pi)) + d.  They depend on (seed, chain, sweep, site) only, so they are made
-// ahead of the in-order part: by this kernel for block 0, by the idle waves of gibbs_r_diag for the others.
-// ---------------------------------------------------------------------------------------------
-__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
-                                uint32_t k0, uint32_t k1, int lane) {
-    const int n = B0 + 2 * p;                    // B0 is even: both halves of a counter block belong to this tile
-    const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
-    thr_wu[(2 * p) * 64 + lane] = fcd_logit(fcd_u53(x.x, x.y));
-    thr_wu[(2 * p + 1) * 64 + lane] = fcd_logit(fcd_u53(x.z, x.w));
-}
-
-// f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
-__device__ inline uint32_t f_of(uint32_t word, int j) {
-    const uint32_t q = (word >> (4 * (j >> 1))) & 15u;
-    const uint32_t hi = (q * 11u) >> 5;          // q / 3 for q in 0..8
-    return (j & 1) ? q - 3u * hi : hi;
-}
-
-// ---------------------------------------------------------------------------------------------
-// diagonal kernel.  grid = (U, GW); block = 4 waves = ONE (patient, chain word).
-// Phase A, all four waves: stage the diagonal tile lMd[u][B0+i][B0+j]; wave q takes rows i = q, q+4, ..:
-//   panel sum + the terms against the OLD r_j of later regions j > i of the block.
-// Phase B: wave 0 walks the 16 regions in order: compare -> for j > i: d_j += term(j, i; r_i) -- all LDS reads
-//   of a step are issued before the first add, and there is no exp / division / RNG on the chain;
-//   meanwhile waves 1..3 compute the NEXT block's thresholds (Philox + logit) for the next launch.
-// ---------------------------------------------------------------------------------------------
-constexpr int D_WAVES = 4;
-__global__ __launch_bounds__(64 * D_WAVES) void gibbs_r_diag(const double *__restrict__ lMd, const double *__restrict__ hyper,
-                                                             const uint32_t *__restrict__ f_r, uint16_t *__restrict__ r_T,
-                                                             uint64_t *__restrict__ r_bits, const double *__restrict__ P,
-                                                             const double *__restrict__ thr_cur, double *__restrict__ thr_next,
-                                                             int Nreg, int U, int NBLK, int b_own, int nb, int sb0, int sb1,
-                                                             int prow, uint32_t chain0, uint64_t seed, uint32_t sweep) {
-    __shared__ double tile[R_NB * R_NB * 6];   // [i][j][k][t]
-    __shared__ double sh_d[R_NB][64];
-    __shared__ uint32_t sh_fp[R_NB][64];
-    const int u = blockIdx.x, w = blockIdx.y;
-    const int B0 = b_own * R_NB;
+// Role D: one workgroup = one patient x one group of chain words; one wave = one (patient, chain word) scan.
+// LDS: pair records [2][16][8][36] of the tiles (block b, block b-1) and (block b, block b); the single records are
+// staged into the same space first and each thread keeps its sums in registers across a barrier.
+// Per region i, in order:  d = panel sum + 8 pair terms against block b-1 + 8 pair terms against the own block
+// (the already redrawn bits below i, the old bits above i; the record of (i, i) is zero), compare with the
+// threshold.  All reads of a row are independent; only the 1-bit decision links one row to the next.
+constexpr int D_RECS_T = R_NB * (R_NB / 2);             // pair records of one tile
+constexpr int D_SAFE = 104;                             // records of tile 1 that end before single B starts (compact layout)
+__device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, double *smem) {
+    const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
+    const int u = item % U, wg = item / U;
+    const int b = a.s - 1, B0 = b * R_NB;
+    const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
+    const bool hasA = b > 0;
+    // LDS (doubles): pair records [tile][i][p][36], tile 0 = columns of block b-1, tile 1 = own block; the single
+    // records [i][j][6] of both tiles are staged first.  A full workgroup keeps to D_LDS_COMPACT: single A sits where
+    // pair tile 1 will go, single B over its last D_RECS_T - D_SAFE records (built from registers across a barrier);
+    // a smaller workgroup (fewer chain words) gets the singles behind the pairs.
+    const bool compact = blockDim.x == 1024;
+    double *pairs = smem;
+    double *sA = compact ? smem + D_RECS_T * 36 : smem + 2 * D_RECS_T * 36;
+    double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
+    if (FCD_ABL(2, 5)) return;           // ablation: empty role
+    {
+        const double *rowbase = a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6;
+        for (int t = threadIdx.x; t < R_NB * R_NB * 6; t += blockDim.x) {
+            const int i = t / (R_NB * 6), j6 = t - i * (R_NB * 6);
+            const double *src = rowbase + (int64_t)i * Nreg * 6 + (int64_t)B0 * 6 + j6;
+            sB[t] = (i < nb && j6 < nb * 6) ? src[0] : 0.0;       // beyond Nreg: zero records
+            sA[t] = (hasA && i < nb) ? src[-R_NB * 6] : 0.0;
+        }
+    }
     const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int t = threadIdx.x; t < nb * nb * 6; t += blockDim.x) {
-        const int j6 = t % (nb * 6), i = t / (nb * 6);
-        tile[i * R_NB * 6 + j6] = lMd[(((int64_t)u * Nreg + B0 + i) * Nreg + B0) * 6 + j6];
-    }
-    const int64_t wu = (int64_t)w * U + u;
-    uint16_t *__restrict__ rTw = r_T + (wu * NBLK + b_own) * 64 + lane;
-    const uint32_t old = *rTw;
-    const double *__restrict__ Pw = P + (wu * prow + (b_own - sb0) * R_NB) * 64 + lane;
-    const uint32_t *__restrict__ frw = f_r + (((int64_t)w * Nreg + B0) * NBLK + b_own) * 64 + lane;
-    const char *tb = reinterpret_cast<const char *>(tile);
-
-    // rows i = q, q+4, q+8, q+12: f words, panel sums; the chain wave also requests its thresholds now
-    uint32_t fp[4];
-    double d[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = q + 4 * a;
-        const bool on = i < nb;
-        fp[a] = on ? frw[(int64_t)i * NBLK * 64] : 0u;
-        d[a] = on ? Pw[i * 64] : 0.0;
-    }
-    // The other blocks of the superblock (left out of the panel): whatever r_T holds for them IS the value the scan
-    // needs -- already redrawn for earlier blocks, still old for later ones.  Their 16 terms per row come straight
-    // from the table in L2 (64 independent 8-byte gathers per wave and block: all issued, then added).
-    for (int bo = sb0; bo < sb1; ++bo) {
-        if (bo == b_own) continue;
-        const uint32_t ro = rTw[(int64_t)(bo - b_own) * 64];
-        const int mo = (Nreg - bo * R_NB < R_NB) ? (Nreg - bo * R_NB) : R_NB;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = q + 4 * a;
-            if (i < nb) {
-                const uint32_t fo = frw[(int64_t)i * NBLK * 64 + (int64_t)(bo - b_own) * 64];
-                const char *row = reinterpret_cast<const char *>(lMd + (((int64_t)u * Nreg + B0 + i) * Nreg + bo * R_NB) * 6);
-                double tmp[R_NB];
-#pragma unroll
-                for (int j = 0; j < R_NB; ++j) {
-                    const uint32_t t = (ro >> j) & 1u;
-                    tmp[j] = (j < mo) ? *reinterpret_cast<const double *>(row + j * 48 + (f_of(fo, j) << 4) + (t << 3)) : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < R_NB; ++j) d[a] += tmp[j];
-            }
+    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
+    const bool live = w < a.GW;
+    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
+    // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
+    uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
+    const uint32_t *__restrict__ frw = a.f_r + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
+    const double *__restrict__ Pw = a.P_r + (wu * R_NB) * 64;
+    const double *__restrict__ Tw = a.thr_r + (wu * R_NB) * 64;
+    __syncthreads();
+    {
+        // pair records: each thread keeps one of the 36 (q, tt) entries; record (i, p) <- singles (i*16 + 2p) * 6
+        const int e = threadIdx.x % 36, step = blockDim.x / 36;
+        const int q = e >> 2, tt = e & 3;
+        const int k = q / 3, k2 = q - 3 * k;
+        const int o0 = k * 2 + (tt & 1), o1 = k2 * 2 + (tt >> 1);
+        const int r0 = threadIdx.x / 36;
+        const bool on = (int)threadIdx.x < step * 36;
+        if (on)
+            for (int rec = r0; rec < D_RECS_T; rec += step) pairs[rec * 36 + e] = sA[rec * 12 + o0] + sA[rec * 12 + 6 + o1];
+        __syncthreads();                                  // single A is free: tile 1 may overwrite it
+        const int safe = compact ? D_SAFE : D_RECS_T;
+        if (on)
+            for (int rec = r0; rec < safe; rec += step)
+                pairs[(D_RECS_T + rec) * 36 + e] = sB[rec * 12 + o0] + sB[rec * 12 + 6 + o1];
+        if (compact) {                                    // the records single B sits on: one entry per thread
+            const int rec = D_SAFE + r0;
+            const bool mine = on && rec < D_RECS_T;
+            const double v = mine ? sB[rec * 12 + o0] + sB[rec * 12 + 6 + o1] : 0.0;
+            __syncthreads();
+            if (mine) pairs[(D_RECS_T + rec) * 36 + e] = v;
         }
     }
-    double thr[R_NB];
-    if (q == 0) {
+    // state of the scan and the first rows' operands: requested before the last barrier (the pair build needs the registers)
+    const uint32_t rold = rTw[lane];
+    const uint32_t rprev = hasA ? (uint32_t)rTw[lane - 64] : 0u;
+    constexpr int PF = 2;                // rows in flight (64 VGPRs)
+    uint32_t fa[PF], fb[PF];
+    double base[PF], th[PF];
 #pragma unroll
-        for (int i = 0; i < R_NB; ++i) thr[i] = thr_cur[(wu * R_NB + i) * 64 + lane];
-    }
-    __syncthreads();     // tile staged
-    if (FCD_ABL(2, 3)) return;           // ablation: staging + loads
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = q + 4 * a;
-        // terms against regions of the block that come later in the scan: their OLD value.
-        // All reads first, then the adds: one LDS latency per row instead of one per term.
-        double tmp[R_NB];
-#pragma unroll
-        for (int j = 1; j < R_NB; ++j) {
-            const bool on = j > i && j < nb;
-            const uint32_t t = (old >> j) & 1u;
-            tmp[j] = on ? *reinterpret_cast<const double *>(tb + (f_of(fp[a], j) << 4) + (t << 3) +
-                                                            (uint32_t)((i * R_NB + j) * 48))
-                        : 0.0;
-        }
-#pragma unroll
-        for (int j = 1; j < R_NB; ++j) d[a] += tmp[j];
-        sh_d[i][lane] = d[a];
-        sh_fp[i][lane] = fp[a];
+    for (int i = 0; i < PF - 1; ++i) {
+        const int ii = i < nb ? i : nb - 1;
+        fb[i] = frw[(int64_t)ii * NBLK * 64 + lane];
+        fa[i] = hasA ? frw[(int64_t)ii * NBLK * 64 - 64 + lane] : 0u;
+        base[i] = Pw[ii * 64 + lane];
+        th[i] = Tw[ii * 64 + lane];
     }
     __syncthreads();
-    if (q != 0) {
-        // next block's thresholds on the otherwise idle waves: pairs 0-2, 3-5, 6-7
-        if (b_own + 1 < NBLK) {
-            double *thr_wu = thr_next + (wu * R_NB) * 64;
-            const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-            const int p0 = (q - 1) * 3, p1 = (q == 3) ? 8 : p0 + 3;
-            for (int p = p0; p < p1; ++p)
-                thr_pair(thr_wu, B0 + R_NB, p, U, u, chain, sweep, (uint32_t)seed, (uint32_t)(seed >> 32), lane);
-        }
-        return;
-    }
-    if (FCD_ABL(2, 2)) return;           // ablation: no in-order part
-
-    // the in-order part, one wave
-    const double dpi = hyper[FCD_H_LNPI1] - hyper[FCD_H_LNPI0];
-    double dd[R_NB];
-    uint32_t ff[R_NB];
+    if (!live || FCD_ABL(2, 3)) return;
+    const double dpi = a.hyper[FCD_H_LNPI1] - a.hyper[FCD_H_LNPI0];
+    const char *pa = reinterpret_cast<const char *>(pairs);
+    // (t, t') bits of every pair at bits 3..4: block b-1 fixed; own block updated as the scan moves
+    uint32_t ra[R_NB / 2], rbv[R_NB / 2];
 #pragma unroll
-    for (int i = 0; i < R_NB; ++i) {
-        dd[i] = sh_d[i][lane];
-        ff[i] = sh_fp[i][lane];
+    for (int p = 0; p < R_NB / 2; ++p) {
+        ra[p] = ((rprev >> (2 * p)) & 3u) << 3;
+        rbv[p] = ((rold >> (2 * p)) & 3u) << 3;
     }
     uint32_t fresh = 0;
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         if (i < nb) {
-            const uint32_t t = thr[i] < (dpi + dd[i]) ? 1u : 0u;
+            {
+                const int in = i + PF - 1, sl = in % PF;
+                const int ii = in < nb ? in : nb - 1;
+                fb[sl] = frw[(int64_t)ii * NBLK * 64 + lane];
+                fa[sl] = hasA ? frw[(int64_t)ii * NBLK * 64 - 64 + lane] : 0u;
+                base[sl] = Pw[ii * 64 + lane];
+                th[sl] = Tw[ii * 64 + lane];
+            }
+            const int sl = i % PF;
+            double d = base[sl];
+            if (FCD_ABL(2, 2)) { fresh |= (th[sl] < d + (double)(fa[sl] + fb[sl]) ? 1u : 0u) << i; continue; }
+            {
+                double tmp[R_NB / 2];
+#pragma unroll
+                for (int p = 0; p < R_NB / 2; ++p) {
+                    const uint32_t ad = (((fa[sl] >> (4 * p)) & 15u) << 5) | ra[p];
+                    tmp[p] = *reinterpret_cast<const double *>(pa + ad + (uint32_t)((i * (R_NB / 2) + p) * 288));
+                }
+#pragma unroll
+                for (int p = 0; p < R_NB / 2; ++p) d += tmp[p];
+            }
+            {
+                double tmp[R_NB / 2];
+#pragma unroll
+                for (int p = 0; p < R_NB / 2; ++p) {
+                    const uint32_t ad = (((fb[sl] >> (4 * p)) & 15u) << 5) | rbv[p];
+                    tmp[p] = *reinterpret_cast<const double *>(pa + ad + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
+                }
+#pragma unroll
+                for (int p = 0; p < R_NB / 2; ++p) d += tmp[p];
+            }
+            const uint32_t t = th[sl] < (dpi + d) ? 1u : 0u;
             fresh |= t << i;
-            double tmp[R_NB];
-#pragma unroll
-            for (int j = i + 1; j < R_NB; ++j)
-                tmp[j] = (j < nb) ? *reinterpret_cast<const double *>(tb + (f_of(ff[j], i) << 4) + (t << 3) +
-                                                                      (uint32_t)((j * R_NB + i) * 48))
-                                  : 0.0;
-#pragma unroll
-            for (int j = i + 1; j < R_NB; ++j) dd[j] += tmp[j];
+            // region i now carries its new value for the rows below
+            rbv[i >> 1] = (rbv[i >> 1] & ~(8u << (i & 1))) | (t << (3 + (i & 1)));
         }
     }
-    *rTw = (uint16_t)fresh;
+    rTw[lane] = (uint16_t)fresh;
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         if (i < nb) {
             const uint64_t ball = __ballot((fresh >> i) & 1u);
-            if (lane == 0) r_bits[((int64_t)w * Nreg + B0 + i) * U + u] = ball;
+            if (lane == 0) a.r_bits[((int64_t)w * Nreg + B0 + i) * U + u] = ball;
         }
     }
+}
+
+template <int UB, int WPE>
+__global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_args a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // D workgroups first: few, and the longest dependent chain (dispatching a 16-wave workgroup takes ~15 ns)
+    const int blk = blockIdx.x;
+    if (blk < a.nD) r_role_diag(a, blk, smem);
+    else r_role_panel<UB>(a, blk - a.nD, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -612,20 +645,15 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
     for (int n = tid; n < Nreg; n += 64 * R_WAVES) rcol[(int64_t)n * U] = mask[n];
 }
 
-template <int UB>
-int launch_panel(fcd_ctx *ctx, const double *lMd, const uint32_t *f_r, const uint16_t *r_T, double *P, int64_t Nreg, int64_t U, int NBLK,
-                 const fcd_geo &g, int sb0, int sb1, int n_rows, int prow, hipStream_t s) {
-    const int wpb = g.GW < 16 ? g.GW : 16;
-    const size_t shmem = ((size_t)NBLK * (R_NB / 2) * UB * 36 + (size_t)UB * Nreg * 6) * sizeof(double);
+template <int UB, int WPE>
+int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s) {
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_r_panel<UB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid((unsigned)n_rows, (unsigned)((U + UB - 1) / UB), (unsigned)((g.GW + wpb - 1) / wpb));
     fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
-    hipLaunchKernelGGL(gibbs_r_panel<UB>, grid, dim3(64 * wpb), shmem, s, lMd, f_r, r_T, P, (int)Nreg, (int)U, NBLK, g.GW,
-                       sb0, sb1, prow);
+    hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP)), dim3(64 * a.wpb), shmem, s, a);
     fcd_prof_end(ctx, FCD_PROF_PANEL, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
@@ -717,28 +745,26 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
             return FCD_OK;
         }
     }
-    // blocked path.  Workspace: P | f_r | r_T
+    // blocked path.  Workspace: P[2] | thr[2] | f_r | r_T
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
-    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one threshold buffer
-    const size_t p_bytes = 8 * t_bytes;                                          // P: up to 8 blocks per superblock
+    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel sums / thresholds
     const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint32_t);
     const size_t r_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t);
-    if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX)
+    if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX || (int64_t)g.GW * U * R_NB > INT32_MAX / 64)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, p_bytes + 2 * t_bytes + f_bytes + r_bytes + 512);
+    rc = fcd_ws_reserve(ctx, 4 * t_bytes + f_bytes + r_bytes + 512);
     if (rc) return rc;
-    double *P = (double *)ctx->ws;
-    double *thr[2] = {P + p_bytes / sizeof(double), P + (p_bytes + t_bytes) / sizeof(double)};
-    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + p_bytes + 2 * t_bytes);
-    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + p_bytes + 2 * t_bytes + f_bytes);
+    double *Pb[2] = {(double *)ctx->ws, (double *)((char *)ctx->ws + t_bytes)};
+    double *thr[2] = {(double *)((char *)ctx->ws + 2 * t_bytes), (double *)((char *)ctx->ws + 3 * t_bytes)};
+    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 4 * t_bytes);
+    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 4 * t_bytes + f_bytes);
     {
         const int64_t items_f = (int64_t)g.GW * Nreg * NBLK, items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
                            (int)g.C, edge_mode, f_r);
         FCD_LAUNCH_CHECK();
-        const int64_t items_t = (int64_t)g.GW * U * (R_NB / 2);       // + thresholds of block 0
-        hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + items_t + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg,
-                           (int)U, NBLK, g.GW, r_T, thr[0], (uint32_t)chain0, seed, (uint32_t)sweep);
+        hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
+                           g.GW, r_T);
         FCD_LAUNCH_CHECK();
     }
     fcd_abl_refresh(s);
@@ -751,35 +777,29 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_u <= 156 * 1024) ub = v;
     }
-    // Superblocks of SB blocks: one panel launch per superblock, then its diagonal kernels in order (each adds the
-    // other blocks of its superblock itself).  SB = 1 measured best at cfg3 (598 us vs 631 / 739 for SB = 2 / 4).
-    int SB = 1;
-    if (const char *e = getenv("FCD_R_SB")) {   // tuning knob
-        const int v = atoi(e);
-        if (v >= 1 && v <= 8) SB = v;
+    size_t shmem = (size_t)ub * per_u;
+    {
+        const size_t d_need = (size_t)(g.GW < 16 ? D_LDS_SPREAD : D_LDS_COMPACT) * sizeof(double);
+        if (shmem < d_need) shmem = d_need;
     }
-    const int prow = SB * R_NB;
-    for (int sb0 = 0; sb0 < NBLK; sb0 += SB) {
-        const int sb1 = (sb0 + SB < NBLK) ? sb0 + SB : NBLK;
-        const int n_rows = (int)(((int64_t)sb1 * R_NB < Nreg ? (int64_t)sb1 * R_NB : Nreg) - (int64_t)sb0 * R_NB);
-        if (sb0 > 0 || sb1 < NBLK) {   // something outside the superblock
-            if (ub == 4) rc = launch_panel<4>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
-            else if (ub == 2) rc = launch_panel<2>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
-            else rc = launch_panel<1>(ctx, lMd, f_r, r_T, P, Nreg, U, NBLK, g, sb0, sb1, n_rows, prow, s);
-            if (rc) return rc;
-        } else {
-            FCD_HIP_TRY(hipMemsetAsync(P, 0, (size_t)g.GW * U * prow * 64 * sizeof(double), s));
-        }
-        for (int b = sb0; b < sb1; ++b) {
-            const int nb = (Nreg - b * R_NB < R_NB) ? (int)(Nreg - b * R_NB) : R_NB;
-            dim3 grid((unsigned)U, (unsigned)g.GW);
-            fcd_prof_begin(ctx, FCD_PROF_DIAG, s);
-            hipLaunchKernelGGL(gibbs_r_diag, grid, dim3(64 * D_WAVES), 0, s, lMd, hyper, f_r, r_T, r_bits, P, thr[b & 1],
-                               thr[(b + 1) & 1], (int)Nreg, (int)U, NBLK, b, nb, sb0, sb1, prow, (uint32_t)chain0, seed,
-                               (uint32_t)sweep);
-            fcd_prof_end(ctx, FCD_PROF_DIAG, s);
-            FCD_LAUNCH_CHECK();
-        }
+    r_step_args a;
+    a.lMd = lMd; a.hyper = hyper; a.f_r = f_r; a.r_T = r_T; a.r_bits = r_bits;
+    a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;
+    a.wpb = g.GW < 16 ? g.GW : 16;
+    a.nWG = (g.GW + a.wpb - 1) / a.wpb;
+    a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
+    const int nUC = (int)((U + ub - 1) / ub);
+    for (int st = 0; st <= NBLK; ++st) {
+        const int rows = st < NBLK ? (int)((Nreg - (int64_t)st * R_NB < R_NB) ? (Nreg - (int64_t)st * R_NB) : R_NB) : 0;
+        a.s = st;
+        a.nD = st >= 1 ? (int)U * a.nWG : 0;
+        a.nP = rows * nUC * a.nWG;
+        a.P_w = Pb[st & 1]; a.P_r = Pb[(st + 1) & 1];
+        a.thr_w = thr[st & 1]; a.thr_r = thr[(st + 1) & 1];
+        if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s);
+        else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s);
+        else rc = launch_step<1, 8>(ctx, a, shmem, s);
+        if (rc) return rc;
     }
     return FCD_OK;
 }

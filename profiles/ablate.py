@@ -37,6 +37,9 @@ def main():
     cases = [("f full", "f", {}), ("f no-draw", "f", {"FCD_ABL_F": "2"}), ("f staging-only", "f", {"FCD_ABL_F": "3"}),
              ("r full", "r", {}),
              ("r panel loads-only", "r", {"FCD_ABL_PANEL": "2"}), ("r panel staging-only", "r", {"FCD_ABL_PANEL": "3"}),
+             ("r panel single rows only", "r", {"FCD_ABL_PANEL": "4"}), ("r panel empty", "r", {"FCD_ABL_PANEL": "5"}),
+             ("r diag no next-thresholds", "r", {"FCD_ABL_DIAG": "1"}), ("r diag empty", "r", {"FCD_ABL_DIAG": "5"}),
+             ("r panel empty + diag empty", "r", {"FCD_ABL_PANEL": "5", "FCD_ABL_DIAG": "5"}),
              ("r diag no-chain", "r", {"FCD_ABL_DIAG": "2"}), ("r diag prologue-only", "r", {"FCD_ABL_DIAG": "3"}),
              ("r panel staging-only + diag prologue-only", "r", {"FCD_ABL_PANEL": "3", "FCD_ABL_DIAG": "3"})]
     res = {name: [] for (name, _, _) in cases}
