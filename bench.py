@@ -134,8 +134,8 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # Per-kernel durations: one HIP event pair around EVERY f / panel / diagonal launch costs ~3.7 us per event
-    # (54 per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right
+    # Per-kernel durations: one HIP event pair around EVERY f / step launch costs ~3.7 us per event
+    # (30 per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right
     # after it with the pairs enabled, and only that second pass feeds the per-kernel numbers.
     ctx.prof_enable(True)
     for s in range(args.warmup + args.steps, args.warmup + 2 * args.steps):
@@ -151,12 +151,12 @@ def main():
     # algorithmic bytes, SURVEY.md section 8d (u8 state): lM once per pass + state
     f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
     r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
-    n_panel = max(kern["gibbs_r_panel"]["launches"] // max(args.steps, 1), 1)     # panel launches per pass
+    kern.pop("gibbs_r_diag", None)                                                # (slot unused: the in-order part rides in the step kernel)
+    n_step = max(kern["gibbs_r_step_kernel"]["launches"] // max(args.steps, 1), 1)   # step launches per pass
     per_launch_bytes = {"gibbs_f_pair_kernel": f_bytes,
-                        # a panel launch serves 16 of the Nreg regions' rows of the r pass
-                        "gibbs_r_panel": r_bytes / n_panel,
-                        "gibbs_r_diag": 0.0}
-    dom = max(("gibbs_f_pair_kernel", "gibbs_r_panel"), key=lambda k: kern[k]["total_ms"])
+                        # a step launch serves 16 of the Nreg regions' rows of the r pass
+                        "gibbs_r_step_kernel": r_bytes / n_step}
+    dom = max(("gibbs_f_pair_kernel", "gibbs_r_step_kernel"), key=lambda k: kern[k]["total_ms"])
     dom_ms = kern[dom]["avg_launch_ms"]
     dom_bytes = per_launch_bytes[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9

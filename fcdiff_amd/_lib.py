@@ -16,6 +16,7 @@ FCD_ERR_ARG = -1
 FCD_ERR_SHAPE = -2
 FCD_ERR_UNSUPPORTED = -3
 FCD_ERR_INDEX = -4
+FCD_ERR_DEVICE = -5
 EDGE_REFERENCE = 0
 EDGE_SYMMETRIC = 1
 EDGE_MODES = {"reference": EDGE_REFERENCE, "symmetric": EDGE_SYMMETRIC}
@@ -116,6 +117,8 @@ def check(rc, ctx=None):
         raise IndexError(text)
     if rc == FCD_ERR_UNSUPPORTED:
         raise NotImplementedError(text)
+    if rc == FCD_ERR_DEVICE:
+        raise FcdiffHipError(text)
     raise FcdiffHipError("HIP error %d: %s %s" % (rc, base, msg))
 
 
@@ -146,7 +149,7 @@ class Context(object):
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args), self.handle)
 
-    PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_panel": 2, "gibbs_r_diag": 3}
+    PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "gibbs_r_diag": 3}
 
     def prof_enable(self, on=True):
         self.call("fcd_prof_enable", 1 if on else 0)

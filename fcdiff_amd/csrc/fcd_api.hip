@@ -6,7 +6,11 @@
 #ifdef FCD_ABLATE
 #include <stdlib.h>
 __device__ int fcd_abl_level[4];
+__device__ unsigned long long *fcd_trace_buf;
 void fcd_abl_refresh(hipStream_t s) {
+    unsigned long long *tp = nullptr;
+    if (const char *e = getenv("FCD_TRACE_PTR")) tp = (unsigned long long *)strtoull(e, nullptr, 0);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(fcd_trace_buf), &tp, sizeof(tp), 0, hipMemcpyHostToDevice, s);
     int v[4] = {0, 0, 0, 0};
     if (const char *e = getenv("FCD_ABL_F")) v[0] = atoi(e);
     if (const char *e = getenv("FCD_ABL_PANEL")) v[1] = atoi(e);
@@ -83,6 +87,7 @@ const char *fcd_strerror(int code) {
         case FCD_ERR_SHAPE: return "invalid shape (number of connections must be a triangular number, Nreg >= 2)";
         case FCD_ERR_UNSUPPORTED: return "shape outside what the gfx950 kernels are built for";
         case FCD_ERR_INDEX: return "reference edge id out of range";
+        case FCD_ERR_DEVICE: return "a kernel abandoned a device-side wait; the chain state is unusable";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -105,6 +110,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->log_tab = nullptr;
+    ctx->dev_err = nullptr;
     ctx->prof_on = 0;
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         ctx->prof_ev[i] = nullptr;
@@ -112,7 +118,16 @@ int fcd_ctx_create(fcd_ctx **out) {
     }
     ctx->msg[0] = 0;
     int rc = fcd_ws_reserve(ctx, 1u << 20);
+    if (rc == FCD_OK) {
+        void *pin = nullptr;
+        rc = (int)hipHostMalloc(&pin, sizeof(unsigned), hipHostMallocDefault);
+        if (rc == FCD_OK) {
+            ctx->dev_err = (volatile unsigned *)pin;
+            *ctx->dev_err = 0u;
+        }
+    }
     if (rc) {
+        if (ctx->ws) (void)hipFree(ctx->ws);
         delete ctx;
         return rc;
     }
@@ -143,6 +158,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     hipError_t e = hipSuccess;
     if (ctx->ws) e = hipFree(ctx->ws);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
+    if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
         delete[] ctx->prof_ev[i];

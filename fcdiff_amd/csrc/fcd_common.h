@@ -19,6 +19,7 @@ struct fcd_ctx {
     void *ws;          // reduction / partial-sum workspace
     size_t ws_bytes;
     void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
+    volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     // optional per-kernel timing with HIP events on the launch stream (fcd_prof_enable / fcd_prof_collect)
     int prof_on;
     hipEvent_t *prof_ev[FCD_PROF_SLOTS];   // pairs (begin, end)
@@ -131,6 +132,14 @@ __device__ static inline int fcd_draw_f(double a0, double a1, double a2, double 
 // The threshold depends on the random number only, so it is computed off the region-to-region chain.
 __device__ static inline double fcd_logit(double x) { return log(x / (1.0 - x)); }
 __device__ static inline int fcd_draw_r(double s0, double s1, double x) { return fcd_logit(x) < (s1 - s0) ? 1 : 0; }
+// logit(x) to within FCD_LOGIT_FAST_ERR (absolute) from two hardware fp32 logarithms (8 instructions instead of a
+// double-precision division and logarithm).  A draw decided with it is re-decided with fcd_logit whenever the
+// compared quantity lies within the tolerance, so the outcome is always that of fcd_logit.
+#define FCD_LOGIT_FAST_ERR 2e-5
+__device__ static inline double fcd_logit_fast(double x) {
+    const float a = __log2f((float)x), b = __log2f((float)(1.0 - x));   // x = 0 -> -inf, like fcd_logit
+    return (double)((a - b) * 0.69314718f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -186,7 +195,20 @@ static inline int fcd_geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G
 extern __device__ int fcd_abl_level[4];   // [0] f kernel, [1] panel, [2] diag
 #define FCD_ABL(slot, lvl) (fcd_abl_level[slot] >= (lvl))
 void fcd_abl_refresh(hipStream_t s);
+// Timeline of the r step kernel: record (launch, workgroup) x 8 words of the 100 MHz clock, written by thread 0
+// when FCD_TRACE_PTR names a device buffer (profiles/trace_r.py).
+extern __device__ unsigned long long *fcd_trace_buf;
+#define FCD_TRACE(rec, slot)                                                                      \
+    do {                                                                                          \
+        if (fcd_trace_buf && threadIdx.x == 0) fcd_trace_buf[(size_t)(rec) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#define FCD_TRACE_VAL(rec, slot, v)                                                               \
+    do {                                                                                          \
+        if (fcd_trace_buf && threadIdx.x == 0) fcd_trace_buf[(size_t)(rec) * 8 + (slot)] = (unsigned long long)(v); \
+    } while (0)
 #else
 #define FCD_ABL(slot, lvl) false
+#define FCD_TRACE(rec, slot) do { } while (0)
+#define FCD_TRACE_VAL(rec, slot, v) do { } while (0)
 static inline void fcd_abl_refresh(hipStream_t) {}
 #endif

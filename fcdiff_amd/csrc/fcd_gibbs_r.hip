@@ -93,19 +93,6 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
     r_T[(int64_t)item * 64 + lane] = (uint16_t)v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// thresholds logit(x) of the counter RNG for one block of 16 regions: thr[((w*U + u)*R_NB + i)][lane].
-// r_nu = 1  <=>  thr < ln(pi/(1-pi)) + d.  They depend on (seed, chain, sweep, site) only, so they are made
-// ahead of the in-order part (role T of the step kernel).
-// ---------------------------------------------------------------------------------------------
-__device__ inline void thr_pair(double *__restrict__ thr_wu, int B0, int p, int U, int u, uint32_t chain, uint32_t sweep,
-                                uint32_t k0, uint32_t k1, int lane) {
-    const int n = B0 + 2 * p;                    // B0 is even: both halves of a counter block belong to this tile
-    const fcd_u4 x = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
-    thr_wu[(2 * p) * 64 + lane] = fcd_logit(fcd_u53(x.x, x.y));
-    thr_wu[(2 * p + 1) * 64 + lane] = fcd_logit(fcd_u53(x.z, x.w));
-}
-
 // f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
 __device__ inline uint32_t f_of(uint32_t word, int j) {
     const uint32_t q = (word >> (4 * (j >> 1))) & 15u;
@@ -135,38 +122,96 @@ __device__ inline uint32_t f_of(uint32_t word, int j) {
 struct r_step_args {
     const double *lMd, *hyper;
     const uint32_t *f_r;
-    uint16_t *r_T;
+    const uint16_t *r_T;    // r words before the pass (pack_r): what the blocks above the current one still hold
+    uint16_t *r_Tn;         // r words redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
     uint64_t *r_bits;
-    double *P_w;            // panel sums written by P(s)
-    const double *P_r;      // panel sums of block s-1 read by D(s-1)
-    double *thr_w;          // thresholds written by T(s)
-    const double *thr_r;    // thresholds of block s-1
+    double *Pbuf[2];        // e = (dpi + panel sum) - threshold: P(s) writes [s & 1], D(s) reads it
+    uint32_t *flags;        // one-launch form: cntP[wg][uc][s] | cntD[wg][uc][s] | error word; else nullptr
     int Nreg, U, NBLK, GW;
     int wpb, nWG;           // chain words per workgroup, groups of chain words
-    int s, nD, nP;          // step and the number of workgroups per role
+    int s, nD, nP;          // step-per-launch form: the step and the number of workgroups per role
+    int ncu, npad;          // ... CUs of the device; empty workgroups at [ncu, ncu + npad) (beside the D workgroups)
     uint32_t chain0, sweep;
     uint64_t seed;
+    double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
 };
+
+// ---- cross-workgroup hand-over of the one-launch form ----
+// The XCDs' L2 caches are not coherent with each other, and the agent-scope fences that make them so
+// (buffer_wbl2 / buffer_inv) cost tens of microseconds per use here.  So the few arrays that cross workgroups
+// inside the launch (panel sums, thresholds, r words) are read and written with agent-scope accesses (sc1: served
+// by the memory side), everything else stays cached, and the order is kept by hand:
+//   producer: coherent stores; wait until they are acknowledged (vmcnt 0); workgroup barrier; one thread counts up;
+//   consumer: one thread polls the counter (bounded: a wait that outlasts R_SPIN_LIMIT polls raises the error word
+//             and every workgroup drains); workgroup barrier; coherent loads.
+template <bool COH>
+__device__ __forceinline__ double ld_d(const double *p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_d(double *p, double v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_h(const uint16_t *p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_h(uint16_t *p, uint16_t v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+constexpr int R_SPIN_LIMIT = 1 << 18;      // x ~0.3 us per poll
+__device__ __forceinline__ void r_signal(uint32_t *flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint32_t *err, int *sh_ok) {
+    if (threadIdx.x == 0) {
+        int ok = 1, spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(10);
+            if (++spins > R_SPIN_LIMIT) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = *sh_ok != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
 
 constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
 // role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 36 entries <= 1024 threads
 constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
 constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
 
-template <int UB>
-__device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, double *smem) {
+// st = step (block of rows), (row, uc, wg) = region of the block, chunk of patients, group of chain words.
+// wait_flag != nullptr (one-launch form): the r words of blocks <= st-2 are final once *wait_flag >= wait_need.
+// Returns false if that wait was abandoned.
+template <int UB, bool COH>
+__device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int row, int uc, int wg, double *smem,
+                                             const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
-    const int x0 = a.s > 0 ? a.s - 1 : 0, x1 = a.s + 1;       // blocks left out of the sums
-    const int rows = (Nreg - a.s * R_NB < R_NB) ? (Nreg - a.s * R_NB) : R_NB;
+    const int x0 = st > 0 ? st - 1 : 0, x1 = st + 1;       // blocks left out of the sums
+    const int rows = (Nreg - st * R_NB < R_NB) ? (Nreg - st * R_NB) : R_NB;
     const int nUC = (U + UB - 1) / UB;
-    const int row = item % rows, uc = (item / rows) % nUC, wg = item / (rows * nUC);
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
     double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][Nreg*6]
-    const int n = a.s * R_NB + row;
+    const int n = st * R_NB + row;
     const int u0 = uc * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
-    if (FCD_ABL(1, 5)) return;            // ablation: empty role
+    if (FCD_ABL(1, 5)) return true;       // ablation: empty role
+    const int trec = st * 1024 + (int)blockIdx.x;
+    FCD_TRACE(trec, 0);
+    FCD_TRACE_VAL(trec, 6, 1);
+    FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
     {
         const int row_d2 = Nreg * 3;
         double2 *dst = reinterpret_cast<double2 *>(single);
@@ -179,35 +224,61 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, dou
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
     const bool live = w < a.GW;
-    // Thresholds of this block (Philox + logit, consumed by D(s) in the next launch): one (patient, pair of regions)
-    // item per workgroup -- each wave its own chain word -- while the rows above are on their way from memory.
+    // The draw of (n, u) is  r = 1  <=>  logit(x) < ln(pi/(1-pi)) + d.  The threshold logit(x) depends on the counter
+    // RNG only: it is made here (one Philox block per region and PAIR of patients = this workgroup's two patients),
+    // while the rows above are on their way from memory, and leaves with the panel sum as  e = (dpi + sum) - logit~(x);
+    // D(st) adds its terms and tests the sign.  logit~ is the 8-instruction fp32 form: D re-decides with the exact
+    // logit whenever the sum comes within a.tol of zero (a few draws in 10^5), so every outcome is the exact one's.
+    const double dpi = a.hyper[FCD_H_LNPI1] - a.hyper[FCD_H_LNPI0];
+    double th[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) th[u] = 0.0;
     if (live && !FCD_ABL(2, 1)) {
-        const int n_items = U * (R_NB / 2);
-        for (int it = row + rows * uc; it < n_items; it += rows * nUC) {
-            const int p = it % (R_NB / 2), ut = it / (R_NB / 2);
-            if (a.s * R_NB + 2 * p < Nreg)
-                thr_pair(a.thr_w + (((int64_t)w * U + ut) * R_NB) * 64, a.s * R_NB, p, U, ut, a.chain0 + (uint32_t)w * 64u + lane,
-                         a.sweep, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), lane);
+        const uint32_t chain = a.chain0 + (uint32_t)w * 64u + lane;
+        fcd_u4 x = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int uu = u0 + u;
+            if (u == 0 || (uu & 1) == 0)
+                x = fcd_philox((uint32_t)(n * ((U + 1) >> 1) + (uu >> 1)), chain, a.sweep, FCD_KIND_R, (uint32_t)a.seed,
+                               (uint32_t)(a.seed >> 32));
+            th[u] = fcd_logit_fast((uu & 1) ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y));
         }
     }
-    const uint32_t *__restrict__ fr = a.f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64 + lane;
-    const uint16_t *__restrict__ rt[UB];
+    FCD_TRACE(trec, 4);
+    if (wait_flag) {
+        if (!r_wait(wait_flag, wait_need, err, sh_ok)) return false;
+    }
+    FCD_TRACE(trec, 5);
+    // wave-uniform bases (scalar registers) + unsigned 32-bit lane offsets: no per-lane 64-bit pointers
+    const uint32_t ulane = (uint32_t)lane;
+    const uint32_t *__restrict__ fr = a.f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64;
+    // r words: blocks above the current one from the old array, blocks below from the redrawn one
+    // (blocks st-1 and st are loaded with the rest but not used: they come from the old array too, so that no line of
+    // the redrawn array is touched -- and cached -- before it is final)
+    int64_t rt[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
         const int uu = u < nu ? u : nu - 1;
-        rt[u] = a.r_T + ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64 + lane;
+        rt[u] = ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64;
     }
+    const int64_t redrawn = a.r_Tn - a.r_T;          // element distance between the two arrays (wave-uniform select below)
+    auto rword = [&](int u, int b) -> uint32_t {
+        const uint16_t *base = a.r_T + (rt[u] + b * 64 + (b >= st - 1 ? (int64_t)0 : redrawn));
+        return (uint32_t)base[ulane] << 3;
+    };
     // state words of the first group of blocks: issued before the barriers, their latency hides behind the staging
     uint32_t fpv[P_GRP], rwv[P_GRP][UB];
 #pragma unroll
     for (int g = 0; g < P_GRP; ++g) {
         const int b = (g < NBLK) ? g : NBLK - 1;
-        fpv[g] = fr[b * 64];
+        fpv[g] = fr[b * 64 + ulane];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) rwv[g][u] = (uint32_t)rt[u][b * 64] << 3;   // tt*8 sits at bits 3..4 after >> 2p
+        for (int u = 0; u < UB; ++u) rwv[g][u] = rword(u, b);   // tt*8 sits at bits 3..4 after >> 2p
     }
     __syncthreads();
-    if (FCD_ABL(1, 4)) return;            // ablation: single rows staged, no pair records
+    FCD_TRACE(trec, 1);
+    if (FCD_ABL(1, 4)) return true;       // ablation: single rows staged, no pair records
     {
         // pair records: each thread keeps one of the 36 (q, tt) entries and walks the (pair, patient) list
         const int e = threadIdx.x % 36, step = blockDim.x / 36;
@@ -226,25 +297,26 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, dou
         }
     }
     __syncthreads();
-    if (!live) return;
+    FCD_TRACE(trec, 2);
+    if (!live) return true;
     const char *pb = reinterpret_cast<const char *>(pairs);
     double d[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
     constexpr uint32_t REC = UB * 288u;   // bytes per pair of regions in the tile
-    if (FCD_ABL(1, 3)) return;            // ablation: staging only
+    if (FCD_ABL(1, 3)) return true;       // ablation: staging only
 
     // Blocks of 16 regions in groups of P_GRP: the state words of the NEXT group are requested before the
     // current group's terms run, so no global latency sits on the loop.
     for (int bg = 0; bg < NBLK; bg += P_GRP) {
+        // (always loaded, from a clamped block index: a guard around each load turns into a branch and a wait per word)
         uint32_t fpn[P_GRP], rwn[P_GRP][UB];
-        const bool more = bg + P_GRP < NBLK;
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
             const int b = (bg + P_GRP + g < NBLK) ? bg + P_GRP + g : NBLK - 1;
-            fpn[g] = more ? fr[b * 64] : 0u;
+            fpn[g] = fr[b * 64 + ulane];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) rwn[g][u] = more ? (uint32_t)rt[u][b * 64] << 3 : 0u;
+            for (int u = 0; u < UB; ++u) rwn[g][u] = rword(u, b);
         }
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
@@ -273,7 +345,9 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, dou
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-        if (u < nu) a.P_w[(((int64_t)w * U + u0 + u) * R_NB + row) * 64 + lane] = d[u];
+        if (u < nu) st_d<COH>(a.Pbuf[st & 1] + (((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane, (dpi + d[u]) - th[u]);
+    FCD_TRACE(trec, 3);
+    return true;
 }
 
 // Role D: one workgroup = one patient x one group of chain words; one wave = one (patient, chain word) scan.
@@ -284,10 +358,13 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int item, dou
 // threshold.  All reads of a row are independent; only the 1-bit decision links one row to the next.
 constexpr int D_RECS_T = R_NB * (R_NB / 2);             // pair records of one tile
 constexpr int D_SAFE = 104;                             // records of tile 1 that end before single B starts (compact layout)
-__device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, double *smem) {
+// b = block, (u, wg) = patient, group of chain words.  wait_flag != nullptr (one-launch form): the panel sums and
+// thresholds of the block are complete once *wait_flag >= wait_need.  Returns false if that wait was abandoned.
+template <bool COH>
+__device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, int wg, double *smem,
+                                            const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
-    const int u = item % U, wg = item / U;
-    const int b = a.s - 1, B0 = b * R_NB;
+    const int B0 = b * R_NB;
     const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
     const bool hasA = b > 0;
     // LDS (doubles): pair records [tile][i][p][36], tile 0 = columns of block b-1, tile 1 = own block; the single
@@ -298,7 +375,11 @@ __device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, doub
     double *pairs = smem;
     double *sA = compact ? smem + D_RECS_T * 36 : smem + 2 * D_RECS_T * 36;
     double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
-    if (FCD_ABL(2, 5)) return;           // ablation: empty role
+    if (FCD_ABL(2, 5)) return true;      // ablation: empty role
+    const int trec = (b + 1) * 1024 + (int)blockIdx.x;
+    FCD_TRACE(trec, 0);
+    FCD_TRACE_VAL(trec, 6, 2);
+    FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
     {
         const double *rowbase = a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6;
         for (int t = threadIdx.x; t < R_NB * R_NB * 6; t += blockDim.x) {
@@ -313,11 +394,12 @@ __device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, doub
     const bool live = w < a.GW;
     const int64_t wu = (int64_t)(live ? w : 0) * U + u;
     // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
-    uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
+    const uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
+    uint16_t *__restrict__ rTn = a.r_Tn + (wu * NBLK + b) * 64;
     const uint32_t *__restrict__ frw = a.f_r + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
-    const double *__restrict__ Pw = a.P_r + (wu * R_NB) * 64;
-    const double *__restrict__ Tw = a.thr_r + (wu * R_NB) * 64;
+    const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
     __syncthreads();
+    FCD_TRACE(trec, 1);
     {
         // pair records: each thread keeps one of the 36 (q, tt) entries; record (i, p) <- singles (i*16 + 2p) * 6
         const int e = threadIdx.x % 36, step = blockDim.x / 36;
@@ -341,73 +423,87 @@ __device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, doub
             if (mine) pairs[(D_RECS_T + rec) * 36 + e] = v;
         }
     }
-    // state of the scan and the first rows' operands: requested before the last barrier (the pair build needs the registers)
-    const uint32_t rold = rTw[lane];
-    const uint32_t rprev = hasA ? (uint32_t)rTw[lane - 64] : 0u;
-    constexpr int PF = 2;                // rows in flight (64 VGPRs)
-    uint32_t fa[PF], fb[PF];
-    double base[PF], th[PF];
-#pragma unroll
-    for (int i = 0; i < PF - 1; ++i) {
-        const int ii = i < nb ? i : nb - 1;
-        fb[i] = frw[(int64_t)ii * NBLK * 64 + lane];
-        fa[i] = hasA ? frw[(int64_t)ii * NBLK * 64 - 64 + lane] : 0u;
-        base[i] = Pw[ii * 64 + lane];
-        th[i] = Tw[ii * 64 + lane];
-    }
     __syncthreads();
-    if (!live || FCD_ABL(2, 3)) return;
-    const double dpi = a.hyper[FCD_H_LNPI1] - a.hyper[FCD_H_LNPI0];
-    const char *pa = reinterpret_cast<const char *>(pairs);
-    // (t, t') bits of every pair at bits 3..4: block b-1 fixed; own block updated as the scan moves
-    uint32_t ra[R_NB / 2], rbv[R_NB / 2];
-#pragma unroll
-    for (int p = 0; p < R_NB / 2; ++p) {
-        ra[p] = ((rprev >> (2 * p)) & 3u) << 3;
-        rbv[p] = ((rold >> (2 * p)) & 3u) << 3;
+    FCD_TRACE(trec, 2);
+    FCD_TRACE(trec, 4);
+    if (wait_flag) {
+        if (!r_wait(wait_flag, wait_need, err, sh_ok)) return false;
     }
+    FCD_TRACE(trec, 5);
+    if (!live || FCD_ABL(2, 3)) return true;
+    // The scan is the serial chain of the pass (one per patient): its waves go ahead of the panel waves that share the CU.
+    __builtin_amdgcn_s_setprio(3);
+    const char *pa = reinterpret_cast<const char *>(pairs);
+    // Per region i, in order:  v = e_i (= dpi + panel sum - threshold, from P(b)) + 8 pair terms against block b-1 (its
+    // r bits are final) + 8 pair terms against the own block -- redrawn bits below i, old bits above i, the record of
+    // (i, i) is zero -- and the sign test.  All 16 reads of a row are independent; only the 1-bit decision links one
+    // row to the next.  e_i are requested PF_E rows ahead (they come from the memory side), the f words PF_F ahead.
+    const uint32_t ulane = (uint32_t)lane;
+    const uint32_t rold = rTw[ulane];
+    const uint32_t rprev = hasA ? ld_h<COH>(rTn - 64 + ulane) << 3 : 0u;
+    constexpr int PF_E = 4, PF_F = 2;
+    double ev[PF_E];
+    uint32_t fa[PF_F], fb[PF_F];
+#pragma unroll
+    for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
+#pragma unroll
+    for (int i = 0; i < PF_F - 1; ++i) {
+        const uint32_t *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
+        fb[i] = fro[ulane];
+        fa[i] = hasA ? (fro - 64)[ulane] : 0u;
+    }
+    uint32_t rbv[R_NB / 2];
+#pragma unroll
+    for (int p = 0; p < R_NB / 2; ++p) rbv[p] = ((rold >> (2 * p)) & 3u) << 3;
     uint32_t fresh = 0;
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         if (i < nb) {
             {
-                const int in = i + PF - 1, sl = in % PF;
-                const int ii = in < nb ? in : nb - 1;
-                fb[sl] = frw[(int64_t)ii * NBLK * 64 + lane];
-                fa[sl] = hasA ? frw[(int64_t)ii * NBLK * 64 - 64 + lane] : 0u;
-                base[sl] = Pw[ii * 64 + lane];
-                th[sl] = Tw[ii * 64 + lane];
+                const int ie = i + PF_E - 1, jf = i + PF_F - 1;
+                ev[ie % PF_E] = ld_d<COH>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
+                const uint32_t *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
+                fb[jf % PF_F] = fro[ulane];
+                fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : 0u;
             }
-            const int sl = i % PF;
-            double d = base[sl];
-            if (FCD_ABL(2, 2)) { fresh |= (th[sl] < d + (double)(fa[sl] + fb[sl]) ? 1u : 0u) << i; continue; }
+            const uint32_t fwa = fa[i % PF_F], fwb = fb[i % PF_F];
+            double v = ev[i % PF_E];
+            if (FCD_ABL(2, 2)) { fresh |= (v + (double)(fwa + fwb) > 0.0 ? 1u : 0u) << i; continue; }
+            double sa, sb;
             {
-                double tmp[R_NB / 2];
+                double ta[R_NB / 2];
 #pragma unroll
                 for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t ad = (((fa[sl] >> (4 * p)) & 15u) << 5) | ra[p];
-                    tmp[p] = *reinterpret_cast<const double *>(pa + ad + (uint32_t)((i * (R_NB / 2) + p) * 288));
+                    const uint32_t adA = (((fwa >> (4 * p)) & 15u) << 5) | ((rprev >> (2 * p)) & 24u);
+                    ta[p] = *reinterpret_cast<const double *>(pa + adA + (uint32_t)((i * (R_NB / 2) + p) * 288));
                 }
-#pragma unroll
-                for (int p = 0; p < R_NB / 2; ++p) d += tmp[p];
+                sa = ((ta[0] + ta[1]) + (ta[2] + ta[3])) + ((ta[4] + ta[5]) + (ta[6] + ta[7]));
             }
             {
-                double tmp[R_NB / 2];
+                double tb[R_NB / 2];
 #pragma unroll
                 for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t ad = (((fb[sl] >> (4 * p)) & 15u) << 5) | rbv[p];
-                    tmp[p] = *reinterpret_cast<const double *>(pa + ad + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
+                    const uint32_t adB = (((fwb >> (4 * p)) & 15u) << 5) | rbv[p];
+                    tb[p] = *reinterpret_cast<const double *>(pa + adB + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
                 }
-#pragma unroll
-                for (int p = 0; p < R_NB / 2; ++p) d += tmp[p];
+                sb = ((tb[0] + tb[1]) + (tb[2] + tb[3])) + ((tb[4] + tb[5]) + (tb[6] + tb[7]));
             }
-            const uint32_t t = th[sl] < (dpi + d) ? 1u : 0u;
+            v = (v + sa) + sb;
+            if (__ballot(fabs(v) < a.tol) != 0ull) {
+                // too close to call with the fast threshold in e_i: put the exact one in its place
+                const fcd_u4 x = fcd_philox((uint32_t)((B0 + i) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ulane,
+                                            a.sweep, FCD_KIND_R, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                const double xx = (u & 1) ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y);
+                const double corr = fcd_logit_fast(xx) - fcd_logit(xx);
+                if (xx > 0.0) v += corr;                    // (x = 0: both thresholds are -inf, v = +inf already)
+            }
+            const uint32_t t = v > 0.0 ? 1u : 0u;
             fresh |= t << i;
             // region i now carries its new value for the rows below
             rbv[i >> 1] = (rbv[i >> 1] & ~(8u << (i & 1))) | (t << (3 + (i & 1)));
         }
     }
-    rTw[lane] = (uint16_t)fresh;
+    st_h<COH>(rTn + ulane, (uint16_t)fresh);
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         if (i < nb) {
@@ -415,15 +511,78 @@ __device__ __forceinline__ void r_role_diag(const r_step_args &a, int item, doub
             if (lane == 0) a.r_bits[((int64_t)w * Nreg + B0 + i) * U + u] = ball;
         }
     }
+    __builtin_amdgcn_s_setprio(0);
+    FCD_TRACE(trec, 3);
+    return true;
 }
 
+// step-per-launch form: launch s = D(s-1) workgroups, then P(s) workgroups.
+// Workgroups i and i + (number of CUs) land on the same CU (measured: profiles/trace_r.py), and a panel workgroup
+// beside a D workgroup takes 27 us instead of 21 (beside another panel workgroup) or 16 (alone) -- it would set the
+// length of the launch.  So the grid carries nD empty workgroups at [ncu, ncu + nD): the D workgroups keep their CUs
+// to themselves.  (Placement is the dispatcher's business: this is a heuristic, nothing depends on it.)
 template <int UB, int WPE>
 __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_args a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // D workgroups first: few, and the longest dependent chain (dispatching a 16-wave workgroup takes ~15 ns)
     const int blk = blockIdx.x;
-    if (blk < a.nD) r_role_diag(a, blk, smem);
-    else r_role_panel<UB>(a, blk - a.nD, smem);
+    if (blk < a.nD) {
+        r_role_diag<false>(a, a.s - 1, blk % a.U, blk / a.U, smem, nullptr, 0u, nullptr, nullptr);
+    } else {
+        int item = blk - a.nD;
+        if (a.npad) {
+            if (blk >= a.ncu + a.nD) item -= a.npad;
+            else if (blk >= a.ncu) return;
+        }
+        const int rows = (a.Nreg - a.s * R_NB < R_NB) ? (a.Nreg - a.s * R_NB) : R_NB;
+        const int nUC = (a.U + UB - 1) / UB;
+        r_role_panel<UB, false>(a, a.s, item % rows, (item / rows) % nUC, item / (rows * nUC), smem, nullptr, 0u, nullptr, nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-launch form of the same pass.  grid = U + 16 * ceil(U / UB) workgroups, ALL resident at once (the host
+// checks the occupancy): workgroup (u) walks D(0), D(1), ... of its patient, workgroup (row, uc) walks P(0), P(1), ...
+// of its region-of-the-block and patient chunk; groups of chain words one after the other.  The steps of a patient
+// chunk hand over through two counters per (word group, chunk, step):
+//   cntP: panel workgroups of the step that are done   -> D(s) of the chunk's patients may start at rows(s)
+//   cntD: D workgroups of the chunk that finished block s -> P(s+2) of the chunk may start at nu(chunk)
+// Every wait is on work of an earlier step of workgroups that are already running, so the scan cannot stall; the
+// chunks are independent pipelines and drift apart, which keeps the LDS busy while others stage or wait.  No kernel
+// boundary (~5 us each on this part) between the steps.
+// ---------------------------------------------------------------------------------------------
+template <int UB, int WPE>
+__global__ __launch_bounds__(1024, WPE) void gibbs_r_pass_kernel(const r_step_args a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int sh_ok;
+    const int nUC = (a.U + UB - 1) / UB;
+    const int NB = a.NBLK;
+    uint32_t *cntP = a.flags, *cntD = a.flags + (size_t)a.nWG * nUC * NB, *err = a.flags + (size_t)2 * a.nWG * nUC * NB;
+    const int blk = blockIdx.x;
+    if (blk < a.U) {
+        const int u = blk, uc = u / UB;
+        for (int wg = 0; wg < a.nWG; ++wg) {
+            for (int b = 0; b < NB; ++b) {
+                const int rows = (a.Nreg - b * R_NB < R_NB) ? (a.Nreg - b * R_NB) : R_NB;
+                const size_t fi = ((size_t)wg * nUC + uc) * NB + b;
+                if (!r_role_diag<true>(a, b, u, wg, smem, cntP + fi, (uint32_t)rows, err, &sh_ok)) return;
+                r_signal(cntD + fi);
+            }
+        }
+    } else {
+        const int item = blk - a.U;
+        const int row = item % R_NB, uc = item / R_NB;
+        const int nu = (a.U - uc * UB < UB) ? (a.U - uc * UB) : UB;
+        for (int wg = 0; wg < a.nWG; ++wg) {
+            for (int st = 0; st < NB; ++st) {
+                const int rows = (a.Nreg - st * R_NB < R_NB) ? (a.Nreg - st * R_NB) : R_NB;
+                if (row >= rows) continue;
+                const size_t fi = ((size_t)wg * nUC + uc) * NB + st;
+                const uint32_t *wf = st >= 2 ? cntD + fi - 2 : nullptr;
+                if (!r_role_panel<UB, true>(a, st, row, uc, wg, smem, wf, (uint32_t)nu, err, &sh_ok)) return;
+                r_signal(cntP + fi);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,21 +616,21 @@ __global__ __launch_bounds__(256) void pack_f2_kernel(const uint8_t *__restrict_
     f2[(int64_t)item * 64 + lane] = v;
 }
 
-// thr[((w*U + u)*Nreg + n)][lane] for every region: one wave per (w, u, pair of regions)
+// thr[((w*U + u)*Nreg + n)][lane] for every region: one wave per (w, pair of patients, region) = one counter block
 __global__ __launch_bounds__(256) void r_thr_all_kernel(double *__restrict__ thr, int Nreg, int U, int GW, uint32_t chain0,
                                                         uint64_t seed, uint32_t sweep) {
     const int lane = threadIdx.x & 63;
-    const int n_np = (Nreg + 1) / 2;
+    const int U2 = (U + 1) / 2;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (int64_t)GW * U * n_np) return;
-    const int p = (int)(item % n_np);
-    const int64_t wu = item / n_np;
-    const int u = (int)(wu % U), w = (int)(wu / U);
-    const fcd_u4 x = fcd_philox((uint32_t)(p * U + u), chain0 + (uint32_t)w * 64u + lane, sweep, FCD_KIND_R, (uint32_t)seed,
+    if (item >= (int64_t)GW * U2 * Nreg) return;
+    const int n = (int)(item % Nreg);
+    const int64_t wq = item / Nreg;
+    const int uq = (int)(wq % U2), w = (int)(wq / U2);
+    const fcd_u4 x = fcd_philox((uint32_t)(n * U2 + uq), chain0 + (uint32_t)w * 64u + lane, sweep, FCD_KIND_R, (uint32_t)seed,
                                 (uint32_t)(seed >> 32));
-    double *o = thr + (wu * Nreg + 2 * p) * 64 + lane;
+    double *o = thr + (((int64_t)w * U + 2 * uq) * Nreg + n) * 64 + lane;
     o[0] = fcd_logit(fcd_u53(x.x, x.y));
-    if (2 * p + 1 < Nreg) o[64] = fcd_logit(fcd_u53(x.z, x.w));
+    if (2 * uq + 1 < U) o[(int64_t)Nreg * 64] = fcd_logit(fcd_u53(x.z, x.w));
 }
 
 template <int MS>
@@ -635,8 +794,8 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
                 t0 += part[(j * 2 + 0) * 64 + lane];
                 t1 += part[(j * 2 + 1) * 64 + lane];
             }
-            if ((n & 1) == 0) rnd = fcd_philox((uint32_t)((n >> 1) * U + u), chain, sweep, FCD_KIND_R, k0, k1);
-            const double x = (n & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            rnd = fcd_philox((uint32_t)(n * ((U + 1) >> 1) + (u >> 1)), chain, sweep, FCD_KIND_R, k0, k1);
+            const double x = (u & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
             const uint64_t ball = __ballot(fcd_draw_r(lnpi0 + t0, lnpi1 + t1, x));
             if (lane == 0) mask[n] = ball;
         }
@@ -653,7 +812,26 @@ int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s)
         if (e != hipSuccess) return (int)e;
     }
     fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
-    hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP)), dim3(64 * a.wpb), shmem, s, a);
+    hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(64 * a.wpb), shmem, s, a);
+    fcd_prof_end(ctx, FCD_PROF_PANEL, s);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+template <int UB, int WPE>
+int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool *fits, hipStream_t s) {
+    const void *fn = reinterpret_cast<const void *>(&gibbs_r_pass_kernel<UB, WPE>);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return (int)e;
+    }
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * a.wpb, shmem);
+    if (e != hipSuccess) return (int)e;
+    *fits = (int64_t)per_cu * ctx->num_cu >= grid;      // every workgroup resident at once, or no one-launch form
+    if (!*fits) return FCD_OK;
+    fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
+    hipLaunchKernelGGL((gibbs_r_pass_kernel<UB, WPE>), dim3((unsigned)grid), dim3(64 * a.wpb), shmem, s, a);
     fcd_prof_end(ctx, FCD_PROF_PANEL, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
@@ -686,6 +864,7 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
     if (!lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: null pointer");
+    if (ctx->dev_err && *ctx->dev_err) return fcd_fail(ctx, FCD_ERR_DEVICE, "r pass: a device-side wait was abandoned in an earlier call");
     if (edge_mode != FCD_EDGE_REFERENCE && edge_mode != FCD_EDGE_SYMMETRIC)
         return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_r_step: edge_mode %lld", edge_mode);
     if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
@@ -727,7 +906,7 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
                 hipLaunchKernelGGL(pack_f2_kernel<16>, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, g.GW,
                                    (int)g.C, edge_mode, f2);
             FCD_LAUNCH_CHECK();
-            const int64_t items_t = (int64_t)g.GW * U * ((Nreg + 1) / 2);
+            const int64_t items_t = (int64_t)g.GW * ((U + 1) / 2) * Nreg;
             hipLaunchKernelGGL(r_thr_all_kernel, dim3((unsigned)((items_t + 3) / 4)), dim3(256), 0, s, thr_all, (int)Nreg, (int)U, g.GW,
                                (uint32_t)chain0, seed, (uint32_t)sweep);
             FCD_LAUNCH_CHECK();
@@ -745,19 +924,22 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
             return FCD_OK;
         }
     }
-    // blocked path.  Workspace: P[2] | thr[2] | f_r | r_T
+    // blocked path.  Workspace: P[2] | f_r | r_T | r_Tn | flags
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
-    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel sums / thresholds
+    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
     const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint32_t);
-    const size_t r_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t);
+    const size_t r_bytes = ((size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
+    const int nWGs = (g.GW + 15) / 16;
+    const size_t flag_words = (size_t)2 * nWGs * U * NBLK + 1;                   // (at most U chunks) + the error word
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX || (int64_t)g.GW * U * R_NB > INT32_MAX / 64)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, 4 * t_bytes + f_bytes + r_bytes + 512);
+    rc = fcd_ws_reserve(ctx, 2 * t_bytes + f_bytes + 2 * r_bytes + flag_words * sizeof(uint32_t) + 512);
     if (rc) return rc;
     double *Pb[2] = {(double *)ctx->ws, (double *)((char *)ctx->ws + t_bytes)};
-    double *thr[2] = {(double *)((char *)ctx->ws + 2 * t_bytes), (double *)((char *)ctx->ws + 3 * t_bytes)};
-    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 4 * t_bytes);
-    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 4 * t_bytes + f_bytes);
+    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 2 * t_bytes);
+    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes);
+    uint16_t *r_Tn = (uint16_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + r_bytes);
+    uint32_t *flags = (uint32_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + 2 * r_bytes);
     {
         const int64_t items_f = (int64_t)g.GW * Nreg * NBLK, items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
@@ -783,19 +965,50 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
         if (shmem < d_need) shmem = d_need;
     }
     r_step_args a;
-    a.lMd = lMd; a.hyper = hyper; a.f_r = f_r; a.r_T = r_T; a.r_bits = r_bits;
+    a.lMd = lMd; a.hyper = hyper; a.f_r = f_r; a.r_T = r_T; a.r_Tn = r_Tn; a.r_bits = r_bits;
+    a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
+    a.flags = nullptr;
     a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;
     a.wpb = g.GW < 16 ? g.GW : 16;
     a.nWG = (g.GW + a.wpb - 1) / a.wpb;
+    a.s = 0; a.nD = 0; a.nP = 0;
+    a.ncu = ctx->num_cu; a.npad = 0;
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
+    a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
+    if (const char *e = getenv("FCD_R_TOL")) {   // test hook: a huge value sends every draw through the exact path
+        const double v = atof(e);
+        if (v > a.tol) a.tol = v;
+    }
     const int nUC = (int)((U + ub - 1) / ub);
+    // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
+    // measured 472 us against 400 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
+    // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the
+    // hand-over adds waits), see DESIGN.md.
+    int persist = 0;
+    if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
+    if (persist) {
+        const int grid = (int)U + R_NB * nUC;
+        bool fits = false;
+        a.flags = flags;
+        FCD_HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)2 * a.nWG * nUC * NBLK + 1) * sizeof(uint32_t), s));
+        if (ub == 4) rc = launch_pass<4, 4>(ctx, a, shmem, grid, &fits, s);
+        else if (ub == 2) rc = launch_pass<2, 8>(ctx, a, shmem, grid, &fits, s);
+        else rc = launch_pass<1, 8>(ctx, a, shmem, grid, &fits, s);
+        if (rc) return rc;
+        if (fits) {
+            // the error word comes back with the stream; it is looked at by the next call on this context
+            FCD_HIP_TRY(hipMemcpyAsync((void *)ctx->dev_err, flags + (size_t)2 * a.nWG * nUC * NBLK, sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, s));
+            return FCD_OK;
+        }
+        a.flags = nullptr;
+    }
     for (int st = 0; st <= NBLK; ++st) {
         const int rows = st < NBLK ? (int)((Nreg - (int64_t)st * R_NB < R_NB) ? (Nreg - (int64_t)st * R_NB) : R_NB) : 0;
         a.s = st;
         a.nD = st >= 1 ? (int)U * a.nWG : 0;
         a.nP = rows * nUC * a.nWG;
-        a.P_w = Pb[st & 1]; a.P_r = Pb[(st + 1) & 1];
-        a.thr_w = thr[st & 1]; a.thr_r = thr[(st + 1) & 1];
+        a.npad = (a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
         if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s);
         else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s);
         else rc = launch_step<1, 8>(ctx, a, shmem, s);

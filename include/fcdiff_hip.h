@@ -45,6 +45,7 @@ extern "C" {
 #define FCD_ERR_SHAPE (-2)       /* C is not a triangular number (fit.py:62-65), Nreg < 2, ... */
 #define FCD_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (message says which) */
 #define FCD_ERR_INDEX (-4)       /* reference edge ids run out of range (Nreg == 2, fit.py:186) */
+#define FCD_ERR_DEVICE (-5)      /* a kernel gave up a device-side wait (one-launch r pass); the chain state is unusable */
 
 /* Edge id used by the region update for an ordered pair (n, m), m != n. */
 #define FCD_EDGE_REFERENCE 0 /* nm_to_c(n,m) = n(n-1)/2 + m for EVERY ordered pair, as fit.py:185-186 calls it */

@@ -293,8 +293,9 @@ void oracle_gibbs_r_step(const uint8_t *f, uint8_t *r, const double *lM, const d
                     cond[((g * Nreg + n) * U + u) * 2 + 1] = s1;
                 }
                 if (draw) {
-                    const double x = site_uniform(seed, (uint32_t)((n >> 1) * U + u), (uint32_t)(chain0 + g),
-                                                  (uint32_t)sweep, KIND_R, n & 1);
+                    /* sweeps: one counter block per (region, pair of patients) */
+                    const double x = site_uniform(seed, (uint32_t)(n * ((U + 1) >> 1) + (u >> 1)), (uint32_t)(chain0 + g),
+                                                  (uint32_t)sweep, KIND_R, (int)(u & 1));
                     /* r = 1 w.p. sigmoid(s1 - s0): logit(x) < s1 - s0 */
                     rg[n * U + u] = log(x / (1.0 - x)) < (s1 - s0);
                 }

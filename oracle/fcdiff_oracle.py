@@ -466,7 +466,13 @@ def f_site(c):
 
 
 def r_site(n, u, U):
+    """initial state: one counter block per (pair of regions, patient)"""
     return ((n >> 1) * U + u, n & 1)
+
+
+def r_draw_site(n, u, U):
+    """sweeps: one counter block per (region, pair of patients) -- the two patients a panel workgroup serves"""
+    return (n * ((U + 1) >> 1) + (u >> 1), u & 1)
 
 
 # ----------------------------------------------------------------------------------------
@@ -560,7 +566,7 @@ def gibbs_r_step(f, r, lM, lnpi2, seed, sweep, mode=EDGE_SYMMETRIC, chain0=0):
         for n in range(Nreg):
             for u in range(U):
                 (s0, s1) = r_conditional_logits(n, u, f[g], r[g], lM, lnpi2, mode)
-                (idx, half) = r_site(n, u, U)
+                (idx, half) = r_draw_site(n, u, U)
                 r[g, n, u] = draw_r(s0, s1, site_uniform(seed, idx, chain0 + g, sweep, KIND_R, half))
 
 

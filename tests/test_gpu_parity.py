@@ -411,6 +411,35 @@ def test_gibbs_row_sequential_r_pass(env, monkeypatch, N, U, G, mode):
     nptest.assert_array_equal(r_g, r_o)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"FCD_R_PERSIST": "0"}, {"FCD_R_PERSIST": "1"}, {"FCD_R_TOL": "1e30"},
+                                   {"FCD_R_PERSIST": "0", "FCD_R_TOL": "1e30"}, {"FCD_R_UB": "1"}],
+                         ids=["step-per-launch", "one-launch", "exact-thresholds", "step-per-launch-exact", "one-patient"])
+@pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
+def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
+    """
+    Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
+    re-decision path of the fast thresholds (FCD_R_TOL huge: every draw is re-decided with the exact logit) and a
+    one-patient panel give the oracle's chains: several blocks of 16 regions, a partial last block, odd U.
+    """
+    for (k, v) in knobs.items():
+        monkeypatch.setenv(k, v)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    seed = 5 + N
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for s in range(2):
+        eng.sweeps(s, 1)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 64)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
 def test_gibbs_chain_sharding_invariance(env):
     """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
     (N, U, G) = (12, 6, 192)
