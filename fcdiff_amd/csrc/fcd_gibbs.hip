@@ -235,14 +235,15 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
 __global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW32, int GW,
                                                       uint32_t *__restrict__ r_U) {
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);      // (w, n, word)
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));      // (w, n, word): scalar
     if (item >= GW * Nreg * NW32) return;
     const int jw = item % NW32, wn = item / NW32;               // wn = w*Nreg + n
     uint32_t v = 0;
 #pragma unroll 8
     for (int j = 0; j < 32; ++j) {
         const int u = jw * 32 + j;
-        if (u < U) v |= (uint32_t)((r_bits[(int64_t)wn * U + u] >> lane) & 1ull) << j;
+        const uint64_t word = r_bits[(int64_t)wn * U + (u < U ? u : U - 1)];                      // clamped: no branch per load
+        v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
     r_U[(int64_t)item * 64 + lane] = v;
 }

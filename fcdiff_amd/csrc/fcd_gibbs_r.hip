@@ -59,36 +59,55 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
 //   r_T[w][u][b][lane]  uint16: bit j = r_{16 b + j, u} of chain 64 w + lane (2 bits per pair)
 // (f of a region beyond Nreg or of m == n counts as 0; those table records are zero.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int GW,
-                                                     int C32, int mode, uint32_t *__restrict__ f_r) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= GW * Nreg * NBLK) return;
-    const int b = item % NBLK, n = (item / NBLK) % Nreg, w = item / (NBLK * Nreg);
-    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64 + lane;
+// (w, n, b) wave-uniform: all index arithmetic is scalar, 32-bit (C * 64 fits an int, checked by the host)
+__device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32, int mode,
+                                            uint32_t *__restrict__ f_r, int w, int n, int b, int lane) {
+    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64;
+    const int tn = (n * (n - 1)) >> 1;
+    const uint32_t sh = 8u * (uint32_t)(lane & 3);
+    // all 16 loads first (from a clamped, always valid edge: a guard around a load is a branch and a wait per load),
+    // the regions that do not exist or are n itself are masked afterwards
+    uint32_t k[R_NB];
+#pragma unroll
+    for (int j = 0; j < R_NB; ++j) {
+        const int m = b * R_NB + j;
+        const bool on = m < Nreg && m != n;
+        const int mm = on ? m : (n > 0 ? 0 : 1);
+        const int e = (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
+        // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
+        k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
+    }
     uint32_t v = 0;
 #pragma unroll
     for (int p = 0; p < R_NB / 2; ++p) {
         const int m0 = b * R_NB + 2 * p, m1 = m0 + 1;
-        uint32_t k0 = 0, k1 = 0;
-        if (m0 < Nreg && m0 != n) k0 = fw[(int64_t)fcd_pair_to_edge(n, m0, mode) * 64];
-        if (m1 < Nreg && m1 != n) k1 = fw[(int64_t)fcd_pair_to_edge(n, m1, mode) * 64];
+        const uint32_t k0 = (m0 < Nreg && m0 != n) ? k[2 * p] : 0u;
+        const uint32_t k1 = (m1 < Nreg && m1 != n) ? k[2 * p + 1] : 0u;
         v |= (k0 * 3u + k1) << (4 * p);
     }
-    f_r[(int64_t)item * 64 + lane] = v;
+    f_r[(((int64_t)w * Nreg + n) * NBLK + b) * 64 + lane] = v;
+}
+
+// grid (ceil(NBLK / 4), rows n0 .. n1-1, GW): one wave per (w, n, b), no index division
+__global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
+                                                     int mode, uint32_t *__restrict__ f_r, int n0) {
+    const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (b >= NBLK) return;
+    pack_f_item(f_state, Nreg, NBLK, C32, mode, f_r, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
                                                      uint16_t *__restrict__ r_T) {
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: the index math stays off the VALU
     if (item >= GW * U * NBLK) return;
     const int b = item % NBLK, u = (item / NBLK) % U, w = item / (NBLK * U);
     uint32_t v = 0;
 #pragma unroll
     for (int j = 0; j < R_NB; ++j) {
         const int m = b * R_NB + j;
-        if (m < Nreg) v |= (uint32_t)((r_bits[((int64_t)w * Nreg + m) * U + u] >> lane) & 1ull) << j;
+        const uint64_t word = r_bits[((int64_t)w * Nreg + (m < Nreg ? m : Nreg - 1)) * U + u];    // clamped: no branch per load
+        v |= (m < Nreg ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
     r_T[(int64_t)item * 64 + lane] = (uint16_t)v;
 }
@@ -520,7 +539,8 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 // Workgroups i and i + (number of CUs) land on the same CU (measured: profiles/trace_r.py), and a panel workgroup
 // beside a D workgroup takes 27 us instead of 21 (beside another panel workgroup) or 16 (alone) -- it would set the
 // length of the launch.  So the grid carries nD empty workgroups at [ncu, ncu + nD): the D workgroups keep their CUs
-// to themselves.  (Placement is the dispatcher's business: this is a heuristic, nothing depends on it.)
+// to themselves.  (Placement is the dispatcher's business: this is a heuristic, nothing depends on it.  Letting the
+// empty workgroups pack the next step's f words instead of pack_f_kernel was tried: 414 us against 400 us per pass.)
 template <int UB, int WPE>
 __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_args a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -530,8 +550,11 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
     } else {
         int item = blk - a.nD;
         if (a.npad) {
-            if (blk >= a.ncu + a.nD) item -= a.npad;
-            else if (blk >= a.ncu) return;
+            if (blk >= a.ncu + a.nD) {
+                item -= a.npad;
+            } else if (blk >= a.ncu) {
+                return;
+            }
         }
         const int rows = (a.Nreg - a.s * R_NB < R_NB) ? (a.Nreg - a.s * R_NB) : R_NB;
         const int nUC = (a.U + UB - 1) / UB;
@@ -603,7 +626,7 @@ template <int MS>
 __global__ __launch_bounds__(256) void pack_f2_kernel(const uint8_t *__restrict__ f_state, int Nreg, int GW, int C32, int mode,
                                                       uint64_t *__restrict__ f2) {
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);       // (w, n, s)
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));       // (w, n, s)
     if (item >= GW * Nreg * MS) return;
     const int s = item % MS, n = (item / MS) % Nreg, w = item / (MS * Nreg);
     const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64 + lane;
@@ -941,10 +964,7 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     uint16_t *r_Tn = (uint16_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + r_bytes);
     uint32_t *flags = (uint32_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + 2 * r_bytes);
     {
-        const int64_t items_f = (int64_t)g.GW * Nreg * NBLK, items_r = (int64_t)g.GW * U * NBLK;
-        hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, NBLK, g.GW,
-                           (int)g.C, edge_mode, f_r);
-        FCD_LAUNCH_CHECK();
+        const int64_t items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
                            g.GW, r_T);
         FCD_LAUNCH_CHECK();
@@ -980,12 +1000,15 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
         if (v > a.tol) a.tol = v;
     }
     const int nUC = (int)((U + ub - 1) / ub);
+    int persist = 0;
+    if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
+    hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s, f_state,
+                       (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
+    FCD_LAUNCH_CHECK();
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
     // measured 472 us against 400 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
     // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the
     // hand-over adds waits), see DESIGN.md.
-    int persist = 0;
-    if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
     if (persist) {
         const int grid = (int)U + R_NB * nUC;
         bool fits = false;

@@ -46,7 +46,7 @@ def main():
     t0_all = t[..., 0][t[..., 0] > 0].min()
     print("step    role   n   start[min..max] us    end[max] us   dur[mean/max] us  stage  build  terms  wait(mean us)")
     for L in range(nl):
-        for role in (2, 1):
+        for role in (2, 3, 1):
             m = (t[L, :, 6] == role) & (t[L, :, 0] > 0)
             if not m.any():
                 continue
@@ -55,7 +55,7 @@ def main():
             ok = x[:, 3] > 0
             wt = (x[:, 5] - x[:, 4]) / 100.0
             print("%4d    %s %4d   %8.2f .. %8.2f   %8.2f     %6.2f / %6.2f     %5.2f  %5.2f  %5.2f  %5.2f" % (
-                L, "D" if role == 2 else "P", int(m.sum()), st.min(), st.max(), en[ok].max() if ok.any() else -1,
+                L, {1: "P", 2: "D", 3: "F"}[role], int(m.sum()), st.min(), st.max(), en[ok].max() if ok.any() else -1,
                 (en - st)[ok].mean(), (en - st)[ok].max(), (s1 - st).mean(), (s2 - s1).mean(), (en - s2)[ok].mean(),
                 wt.mean()))
         m = t[L, :, 0] > 0
@@ -86,7 +86,7 @@ def main():
                     ph[0][slow].mean(), ph[1][slow].mean(), ph[2][slow].mean(), ph[0][pm].mean(), ph[1][pm].mean(), ph[2][pm].mean()))
                 xs = (hw >> 16) & 0xf
                 print("        mean P duration by XCD: %s" % np.round([dur[pm & (xs == k)].mean() for k in range(8)], 1))
-                it = idx - 50 - np.where(idx >= 306, 50, 0)
+                it = idx - 50 - np.where(idx >= 306, 50, 0)   # cfg3: 50 D workgroups first, 50 fillers at 256..305
                 print("        mean P duration by row of the block: %s" % np.round([dur[pm & (it % 16 == k)].mean() for k in range(16)], 1))
                 print("        start of slowest vs all: %.2f vs %.2f us" % ((x3[slow, 0].mean() - x3[pm, 0].min()) / 100.0, (x3[pm, 0].mean() - x3[pm, 0].min()) / 100.0))
                 offs = [abs(int(idx[v[0]]) - int(idx[v[1]])) for v in by.values() if len(v) == 2]
