@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void edge_tables_kernel(const double *__restri
 __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint64_t *__restrict__ r_bits, int Nreg, int U, int64_t C,
-                                                            int GW, int Ec, uint32_t chain0, uint64_t seed, uint32_t sweep) {
+                                                            int GW, int Ec, uint32_t chain0, uint64_t seed, uint32_t sweep,
+                                                            float margin) {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // [Ec][U][3][2]
     const int64_t c0 = (int64_t)blockIdx.x * Ec;
     const int ne = (int)((C - c0 < Ec) ? (C - c0) : Ec);
@@ -220,7 +221,10 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
             rnd = fcd_philox((uint32_t)rnd_idx, chain, sweep, FCD_KIND_F, k0, k1);
         }
         const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
-        f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(0.0, b1, b2, x);
+        bool amb;
+        int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
+        if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);      // too close to a boundary somewhere in the wave
+        f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)k;
     }
 }
 
@@ -253,7 +257,7 @@ template <int NW32>
 __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
-                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep) {
+                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin) {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
     const int NPAIR = (U + 1) >> 1;
     const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
@@ -365,7 +369,10 @@ __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__rest
             }
             if ((e & 1) == 0) rnd = fcd_philox((uint32_t)(c >> 1), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is even
             const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
-            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(0.0, b1, b2, x);
+            bool amb;
+            int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
+            if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
+            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)k;
         }
     }
 }
@@ -725,6 +732,11 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
     fcd_abl_refresh((hipStream_t)stream);
     const int wpb = g.GW < 16 ? g.GW : 16;
     hipStream_t s = (hipStream_t)stream;
+    float margin = FCD_DRAW_F_MARGIN;
+    if (const char *e = getenv("FCD_F_TOL")) {   // test hook: a huge value sends every draw through fcd_draw_f
+        const float v = (float)atof(e);
+        if (v > margin) margin = v;
+    }
     const int NW32 = (int)((U + 31) / 32);
     const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
     if (NW32 <= 2 && pair_shmem <= 96 * 1024 && (int64_t)g.GW * Nreg * NW32 < INT32_MAX / 4) {
@@ -748,10 +760,10 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
         fcd_prof_begin(ctx, FCD_PROF_F, s);
         if (NW32 == 1)
             hipLaunchKernelGGL(gibbs_f_pair_kernel<1>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
-                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
+                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
         else
             hipLaunchKernelGGL(gibbs_f_pair_kernel<2>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
-                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep);
+                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
         fcd_prof_end(ctx, FCD_PROF_F, s);
         FCD_LAUNCH_CHECK();
         return FCD_OK;
@@ -770,7 +782,7 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
     }
     dim3 grid((unsigned)((g.C + e - 1) / e), (unsigned)((g.GW + wpb - 1) / wpb));
     hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), shmem, s, S_B, lMf, hyper, f_state, r_bits,
-                       (int)Nreg, (int)U, g.C, g.GW, (int)e, (uint32_t)chain0, seed, (uint32_t)sweep);
+                       (int)Nreg, (int)U, g.C, g.GW, (int)e, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

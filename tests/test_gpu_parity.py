@@ -413,14 +413,16 @@ def test_gibbs_row_sequential_r_pass(env, monkeypatch, N, U, G, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{"FCD_R_PERSIST": "0"}, {"FCD_R_PERSIST": "1"}, {"FCD_R_TOL": "1e30"},
-                                   {"FCD_R_PERSIST": "0", "FCD_R_TOL": "1e30"}, {"FCD_R_UB": "1"}],
-                         ids=["step-per-launch", "one-launch", "exact-thresholds", "step-per-launch-exact", "one-patient"])
+                                   {"FCD_R_PERSIST": "1", "FCD_R_TOL": "1e30"}, {"FCD_R_UB": "1"}, {"FCD_F_TOL": "1e30"}],
+                         ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
+                              "exact-f-draws"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
     """
     Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
-    re-decision path of the fast thresholds (FCD_R_TOL huge: every draw is re-decided with the exact logit) and a
-    one-patient panel give the oracle's chains: several blocks of 16 regions, a partial last block, odd U.
+    re-decision paths of the fast draws (FCD_R_TOL / FCD_F_TOL huge: every r / f draw is repeated with the exact
+    logit / exponentials) and a one-patient panel give the oracle's chains: several blocks of 16 regions, a partial
+    last block, odd U.
     """
     for (k, v) in knobs.items():
         monkeypatch.setenv(k, v)
