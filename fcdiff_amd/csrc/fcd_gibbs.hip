@@ -234,27 +234,29 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
 // patients (u, u+1): for each of the 16 values of (x_u, x_u+1, a_u, a_u+1), x = r_n xor r_m, a = r_n and r_m,
 //   rec[slot] = lMf[c][u][l(x_u, a_u)][:] + lMf[c][u+1][l(x_u+1, a_u+1)][:]        (2 doubles, 256 B per pair)
 // built in LDS while staging.  One ds_read_b128 + two fp64 adds then cover two patients.  r comes as per-lane
-// words over patients (r_U, made by pack_ru_kernel): no scalar loads inside the loop.
+// words over patients (r_U, made by pack_ru_kernel): no scalar loads inside the loop.  A word holds 16 patients
+// SPREAD over 4-bit fields, the pair (u, u+1) in the low two bits of field u/2: (r_n ^ r_m) | (r_n & r_m) << 2 is
+// then the slot number of every pair at once, and a term costs two integer instructions for its address.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW32, int GW,
+__global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW16, int GW,
                                                       uint32_t *__restrict__ r_U) {
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));      // (w, n, word): scalar
-    if (item >= GW * Nreg * NW32) return;
-    const int jw = item % NW32, wn = item / NW32;               // wn = w*Nreg + n
+    if (item >= GW * Nreg * NW16) return;
+    const int jw = item % NW16, wn = item / NW16;               // wn = w*Nreg + n
     uint32_t v = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-        const int u = jw * 32 + j;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int u = jw * 16 + j;
         const uint64_t word = r_bits[(int64_t)wn * U + (u < U ? u : U - 1)];                      // clamped: no branch per load
-        v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
+        v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << (4 * (j >> 1) + (j & 1));
     }
     r_U[(int64_t)item * 64 + lane] = v;
 }
 
 constexpr int FP_EC = 8;     // edges per tile
-template <int NW32>
-__global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
+template <int NW16>
+__global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
                                                             int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin) {
@@ -273,28 +275,27 @@ __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__rest
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
     // Consecutive edges c = n(n-1)/2 + m share n: its words are fetched once per run, not once per edge.
-    uint32_t X[FP_EC][NW32], A[FP_EC][NW32];
+    uint32_t Z[FP_EC][NW16];      // slot numbers (x_u, x_u+1, a_u, a_u+1) of 8 pairs of patients per word
     if (w < GW) {
-        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW32 * 64 + lane;
+        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW16 * 64 + lane;
         int n, m;
         fcd_edge_to_pair(c0, n, m);
-        uint32_t rn[NW32];
+        uint32_t rn[NW16];
 #pragma unroll
-        for (int j = 0; j < NW32; ++j) rn[j] = ru[(int64_t)(n * NW32 + j) * 64];
+        for (int j = 0; j < NW16; ++j) rn[j] = ru[(int64_t)(n * NW16 + j) * 64];
 #pragma unroll
         for (int e = 0; e < FP_EC; ++e) {
 #pragma unroll
-            for (int j = 0; j < NW32; ++j) {
-                const uint32_t rm = ru[(int64_t)(m * NW32 + j) * 64];
-                X[e][j] = rn[j] ^ rm;
-                A[e][j] = rn[j] & rm;
+            for (int j = 0; j < NW16; ++j) {
+                const uint32_t rm = ru[(int64_t)(m * NW16 + j) * 64];
+                Z[e][j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
             }
             // next edge of the lower-triangular order: (n, m+1), or (n+1, 0) at the end of row n
             if (++m == n) {
                 m = 0;
                 n = (n + 1 < Nreg) ? n + 1 : n;       // past the last edge only for e >= ne (unused)
 #pragma unroll
-                for (int j = 0; j < NW32; ++j) rn[j] = ru[(int64_t)(n * NW32 + j) * 64];
+                for (int j = 0; j < NW16; ++j) rn[j] = ru[(int64_t)(n * NW16 + j) * 64];
             }
         }
     }
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__rest
     const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
-    const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = half a 32-bit word
+    const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
 
 #pragma unroll
     for (int e = 0; e < FP_EC; ++e) {
@@ -339,25 +340,27 @@ __global__ __launch_bounds__(1024) void gibbs_f_pair_kernel(const double *__rest
             const int64_t c = c0 + e;
             const char *tb = reinterpret_cast<const char *>(tile) + (int64_t)e * NPAIR * 256;
             double b1 = 0.0, b2 = 0.0;
-            for (int g = 0; g < NG; ++g) {
-                const uint32_t xs = (g & 1) ? (X[e][(g >> 1) < NW32 ? (g >> 1) : 0] >> 16) : X[e][(g >> 1) < NW32 ? (g >> 1) : 0];
-                const uint32_t as = (g & 1) ? (A[e][(g >> 1) < NW32 ? (g >> 1) : 0] >> 16) : A[e][(g >> 1) < NW32 ? (g >> 1) : 0];
-                const char *gb = tb + g * (8 * 256);
-                if (NPAIR - 8 * g >= 8) {
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        // slot = (x_u, x_u+1, a_u, a_u+1) -> 16-byte records
-                        const uint32_t off = (((xs >> (2 * p)) & 3u) << 4) | (((as >> (2 * p)) & 3u) << 6);
-                        const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
-                        b1 += v.x;
-                        b2 += v.y;
-                    }
-                } else {
-                    for (int p = 0; p < NPAIR - 8 * g; ++p) {
-                        const uint32_t off = (((xs >> (2 * p)) & 3u) << 4) | (((as >> (2 * p)) & 3u) << 6);
-                        const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
-                        b1 += v.x;
-                        b2 += v.y;
+            for (int g = 0; g < NW16; ++g) {
+                if (g < NG) {
+                    const uint32_t zs = Z[e][g];
+                    const char *gb = tb + g * (8 * 256);
+                    if (NPAIR - 8 * g >= 8) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            // slot -> 16-byte records: byte offset = slot << 4
+                            const uint32_t off = (p == 0) ? ((zs << 4) & 0xF0u) : ((zs >> (4 * p - 4)) & 0xF0u);
+                            const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                            b1 += v.x;
+                            b2 += v.y;
+                        }
+                    } else {
+                        for (int p = 0; p < NPAIR - 8 * g; ++p) {
+                            const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
+                            const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                            b1 += v.x;
+                            b2 += v.y;
+                        }
                     }
                 }
             }
@@ -737,33 +740,36 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
         const float v = (float)atof(e);
         if (v > margin) margin = v;
     }
-    const int NW32 = (int)((U + 31) / 32);
+    const int NW16 = (int)((U + 15) / 16);
     const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
-    if (NW32 <= 2 && pair_shmem <= 96 * 1024 && (int64_t)g.GW * Nreg * NW32 < INT32_MAX / 4) {
-        // pair form: per-lane r words over patients (scratch in the ctx workspace), pair records in LDS
-        const size_t ru_bytes = (size_t)g.GW * Nreg * NW32 * 64 * sizeof(uint32_t);
+    if (NW16 <= 4 && pair_shmem <= 96 * 1024 && (int64_t)g.GW * Nreg * NW16 < INT32_MAX / 4) {
+        // pair form: per-lane slot words over patients (scratch in the ctx workspace), pair records in LDS
+        const size_t ru_bytes = (size_t)g.GW * Nreg * NW16 * 64 * sizeof(uint32_t);
         rc = fcd_ws_reserve(ctx, ru_bytes);
         if (rc) return rc;
         uint32_t *r_U = (uint32_t *)ctx->ws;
-        const int64_t items = (int64_t)g.GW * Nreg * NW32;
-        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NW32,
+        const int64_t items = (int64_t)g.GW * Nreg * NW16;
+        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NW16,
                            g.GW, r_U);
         FCD_LAUNCH_CHECK();
         dim3 grid((unsigned)((g.C + FP_EC - 1) / FP_EC), (unsigned)((g.GW + wpb - 1) / wpb));
+        const void *fn = NW16 == 1   ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<1>)
+                         : NW16 == 2 ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<2>)
+                         : NW16 == 3 ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<3>)
+                                     : reinterpret_cast<const void *>(&gibbs_f_pair_kernel<4>);
         if (pair_shmem > 64 * 1024) {
-            hipError_t err = NW32 == 1 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_pair_kernel<1>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem)
-                                       : hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_pair_kernel<2>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem);
+            hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem);
             if (err != hipSuccess) return (int)err;
         }
         fcd_prof_begin(ctx, FCD_PROF_F, s);
-        if (NW32 == 1)
-            hipLaunchKernelGGL(gibbs_f_pair_kernel<1>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
-                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
-        else
-            hipLaunchKernelGGL(gibbs_f_pair_kernel<2>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U,
-                               (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
+#define FCD_LAUNCH_F_PAIR(NW)                                                                                              \
+    hipLaunchKernelGGL(gibbs_f_pair_kernel<NW>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U, (int)Nreg, \
+                       (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin)
+        if (NW16 == 1) FCD_LAUNCH_F_PAIR(1);
+        else if (NW16 == 2) FCD_LAUNCH_F_PAIR(2);
+        else if (NW16 == 3) FCD_LAUNCH_F_PAIR(3);
+        else FCD_LAUNCH_F_PAIR(4);
+#undef FCD_LAUNCH_F_PAIR
         fcd_prof_end(ctx, FCD_PROF_F, s);
         FCD_LAUNCH_CHECK();
         return FCD_OK;
