@@ -100,14 +100,16 @@ def main():
     ev = {"f": [], "r": []}
 
     def step(s, timed):
+        # timed region: the fused driver (f pass + r pass, fcd_gibbs_sweeps) exactly as fit / run_chains use it;
+        # profile pass: the same two passes as separate calls with an event between them (f / r split)
         if timed:
+            eng.sweeps(s, 1)
+        else:
             a, b_, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             a.record()
-        eng.f_step(s)
-        if timed:
+            eng.f_step(s)
             b_.record()
-        eng.r_step(s)
-        if timed:
+            eng.r_step(s)
             c.record()
             ev["f"].append((a, b_))
             ev["r"].append((b_, c))
@@ -123,7 +125,7 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        step(s, False)
+        step(s, True)
     fence()
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):

@@ -111,6 +111,8 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->ws_bytes = 0;
     ctx->log_tab = nullptr;
     ctx->dev_err = nullptr;
+    ctx->fsq = nullptr;
+    ctx->fsq_bytes = 0;
     ctx->prof_on = 0;
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         ctx->prof_ev[i] = nullptr;
@@ -159,6 +161,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->ws) e = hipFree(ctx->ws);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
+    if (ctx->fsq) (void)hipFree(ctx->fsq);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
         delete[] ctx->prof_ev[i];

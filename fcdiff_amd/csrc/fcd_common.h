@@ -20,6 +20,8 @@ struct fcd_ctx {
     size_t ws_bytes;
     void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
+    void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
+    size_t fsq_bytes;
     // optional per-kernel timing with HIP events on the launch stream (fcd_prof_enable / fcd_prof_collect)
     int prof_on;
     hipEvent_t *prof_ev[FCD_PROF_SLOTS];   // pairs (begin, end)
@@ -46,6 +48,15 @@ static inline int fcd_fail(fcd_ctx *ctx, int code, const char *fmt, long long a 
 }
 
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
+// f / r pass with the square copy of the f state (fcd_gibbs_sweeps: the f pass also writes f of edge (n, m) at [n][m] and
+// [m][n], the r pass then packs its f words from contiguous rows instead of gathering 64-byte pieces).  fsq == nullptr:
+// the plain entry points.  Symmetric edge ids only.
+int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
+                        uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq);
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper, const uint8_t *f_state,
+                        uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep,
+                        int edge_mode, hipStream_t stream, const uint8_t *fsq);
 // bracket ONE kernel launch with events when profiling is on (no-ops otherwise)
 void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s);
 void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s);

@@ -259,7 +259,7 @@ template <int NW16>
 __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
-                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin) {
+                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin, uint8_t *__restrict__ fsq) {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
     const int NPAIR = (U + 1) >> 1;
     const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
@@ -333,6 +333,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
     const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
+    int sq_n, sq_m;                      // (n, m) of the edge at hand (wave-uniform walk)
+    fcd_edge_to_pair(c0, sq_n, sq_m);
 
 #pragma unroll
     for (int e = 0; e < FP_EC; ++e) {
@@ -376,6 +378,16 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
             if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
             f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)k;
+            if (fsq) {
+                // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
+                uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64 + lane;
+                sq[((int64_t)sq_n * Nreg + sq_m) * 64] = (uint8_t)k;
+                sq[((int64_t)sq_m * Nreg + sq_n) * 64] = (uint8_t)k;
+            }
+        }
+        if (++sq_m == sq_n) {     // next edge of the lower-triangular order
+            sq_m = 0;
+            ++sq_n;
         }
     }
 }
@@ -725,6 +737,20 @@ extern "C" int fcd_gibbs_edge_tables(fcd_ctx *ctx, const double *lM, int64_t Nre
 extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                                 uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream) {
+    return fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, (hipStream_t)stream,
+                               nullptr);
+}
+
+// *fsq_used (optional) tells the caller whether the kernel that ran writes the square copy (only the pair form does)
+static bool f_step_writes_sq(const double *lMf, int64_t Nreg, int64_t U, int64_t GW) {
+    const int NW16 = (int)((U + 15) / 16);
+    const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
+    return lMf && (size_t)U * 48 <= 160 * 1024 && NW16 <= 4 && pair_shmem <= 96 * 1024 && GW * Nreg * NW16 < INT32_MAX / 4;
+}
+
+int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
+                        uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -764,7 +790,7 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
         fcd_prof_begin(ctx, FCD_PROF_F, s);
 #define FCD_LAUNCH_F_PAIR(NW)                                                                                              \
     hipLaunchKernelGGL(gibbs_f_pair_kernel<NW>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U, (int)Nreg, \
-                       (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin)
+                       (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq)
         if (NW16 == 1) FCD_LAUNCH_F_PAIR(1);
         else if (NW16 == 2) FCD_LAUNCH_F_PAIR(2);
         else if (NW16 == 3) FCD_LAUNCH_F_PAIR(3);
@@ -817,10 +843,28 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
                                 fcd_stream stream) {
     if (n_sweeps < 0 || sweep0 < 0 || sweep0 + n_sweeps > (1ll << 32))
         return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_sweeps: sweep range [%lld, +%lld) outside the 32-bit counter word", sweep0, n_sweeps);
+    // symmetric edge ids + the pair-form f kernel + the blocked r pass: the f pass leaves a square copy of the f state
+    // from which the r pass packs its f words (contiguous rows instead of 64-byte gathers: ~40 us -> ~10 us at cfg3)
+    uint8_t *fsq = nullptr;
+    if (ctx && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 &&
+        f_step_writes_sq(lMf, Nreg, U, (G + 63) / 64)) {
+        const size_t need = (size_t)((G + 63) / 64) * Nreg * Nreg * 64;
+        if (need > ctx->fsq_bytes) {
+            FCD_HIP_TRY(hipDeviceSynchronize());
+            if (ctx->fsq) FCD_HIP_TRY(hipFree(ctx->fsq));
+            ctx->fsq = nullptr;
+            ctx->fsq_bytes = 0;
+            FCD_HIP_TRY(hipMalloc(&ctx->fsq, need));
+            ctx->fsq_bytes = need;
+        }
+        fsq = (uint8_t *)ctx->fsq;
+    }
     for (int64_t i = 0; i < n_sweeps; ++i) {
-        int rc = fcd_gibbs_f_step(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, stream);
+        int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,
+                                     (hipStream_t)stream, fsq);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, stream);
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
+                                 (hipStream_t)stream, fsq);
         if (rc) return rc;
     }
     if (counts && n_sweeps > 0) return fcd_gibbs_stats(ctx, f_state, r_bits, Nreg, U, G, counts, stream);
@@ -863,7 +907,7 @@ extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     hipStream_t s = (hipStream_t)stream;
     if (counts) FCD_HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), s));
     int64_t blocks = (g.C + 15) / 16;
-    const int64_t cap = (int64_t)ctx->num_cu * 2;
+    const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, f_state, r_bits, g.C, Nreg * U, g.GW, G,
                        reinterpret_cast<unsigned long long *>(counts), cnt_f, cnt_r);

@@ -60,9 +60,11 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
 // (f of a region beyond Nreg or of m == n counts as 0; those table records are zero.)
 // ---------------------------------------------------------------------------------------------
 // (w, n, b) wave-uniform: all index arithmetic is scalar, 32-bit (C * 64 fits an int, checked by the host)
+// SQ: f_state is the square copy [w][n][m][lane] (rows contiguous in m) instead of the edge-major state
+template <bool SQ>
 __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32, int mode,
                                             uint32_t *__restrict__ f_r, int w, int n, int b, int lane) {
-    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64;
+    const uint8_t *__restrict__ fw = SQ ? f_state + ((int64_t)w * Nreg + n) * Nreg * 64 : f_state + (int64_t)w * C32 * 64;
     const int tn = (n * (n - 1)) >> 1;
     const uint32_t sh = 8u * (uint32_t)(lane & 3);
     // all 16 loads first (from a clamped, always valid edge: a guard around a load is a branch and a wait per load),
@@ -73,7 +75,7 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
         const int m = b * R_NB + j;
         const bool on = m < Nreg && m != n;
         const int mm = on ? m : (n > 0 ? 0 : 1);
-        const int e = (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
+        const int e = SQ ? mm : (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
         // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
         k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
     }
@@ -89,11 +91,12 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
 }
 
 // grid (ceil(NBLK / 4), rows n0 .. n1-1, GW): one wave per (w, n, b), no index division
+template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
                                                      int mode, uint32_t *__restrict__ f_r, int n0) {
     const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
-    pack_f_item(f_state, Nreg, NBLK, C32, mode, f_r, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
+    pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_r, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
@@ -883,6 +886,13 @@ extern "C" int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t N
 extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                                 const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream) {
+    return fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, edge_mode,
+                               (hipStream_t)stream, nullptr);
+}
+
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper, const uint8_t *f_state,
+                        uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep,
+                        int edge_mode, hipStream_t stream, const uint8_t *fsq) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -1002,8 +1012,12 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
     const int nUC = (int)((U + ub - 1) / ub);
     int persist = 0;
     if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
-    hipLaunchKernelGGL(pack_f_kernel, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s, f_state,
-                       (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
+    if (fsq)
+        hipLaunchKernelGGL(pack_f_kernel<true>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
+                           fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
+    else
+        hipLaunchKernelGGL(pack_f_kernel<false>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
+                           f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
     FCD_LAUNCH_CHECK();
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
     // measured 472 us against 400 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
