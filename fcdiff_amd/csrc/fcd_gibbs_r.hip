@@ -53,17 +53,37 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-pass packing of the chain state into the two forms the blocked kernels read with one coalesced
-// load per 16 regions (= 8 PAIRS of regions (2p, 2p+1)):
-//   f_r[w][n][b][lane]  uint32: 4 bits per pair p of block b: q = 3 f(n, m) + f(n, m+1), m = 16 b + 2 p
-//   r_T[w][u][b][lane]  uint16: bit j = r_{16 b + j, u} of chain 64 w + lane (2 bits per pair)
+// per-pass packing of the chain state into the forms the blocked kernels read with one coalesced load per 16
+// regions (= 8 PAIRS of regions (2p, 2p+1)).  A pair record in LDS is [q = 3 f(n,m) + f(n,m+1)][tt = r_m + 2 r_m+1]
+// doubles, so the byte offset of a term is (q << 5) | (tt << 3) = ((q << 2) | tt) << 3: the words carry ONE BYTE per
+// pair, the f part and the r part of that byte are OR-ed once per block, and a term costs two integer instructions
+// (extract the byte, shift-add the tile base).
+//   f_S[w][n][b][lane]   uint2: byte p (x: pairs 0-3, y: pairs 4-7) = q << 2 of block b
+//   r_S[w][u][b][lane]   uint2: byte p = tt of block b, before the pass; r_Sn likewise, the blocks redrawn in the pass
+//   r_T[w][u][b][lane]   uint16: bit j = r_{16 b + j, u} (what the in-order part D reads and writes); r_Tn likewise
 // (f of a region beyond Nreg or of m == n counts as 0; those table records are zero.)
 // ---------------------------------------------------------------------------------------------
+// 8 two-bit fields of x -> the low two bits of 8 bytes (x: fields 0-3, y: fields 4-7)
+__device__ __forceinline__ uint2 spread2(uint32_t x16) {
+    uint32_t lo = x16 & 0xFFu, hi = (x16 >> 8) & 0xFFu;
+    lo = (lo | (lo << 12)) & 0x000F000Fu;
+    hi = (hi | (hi << 12)) & 0x000F000Fu;
+    lo = (lo | (lo << 6)) & 0x03030303u;
+    hi = (hi | (hi << 6)) & 0x03030303u;
+    return make_uint2(lo, hi);
+}
+// byte p of the pair word -> byte offset inside the pair record ((q << 2 | tt) << 3)
+__device__ __forceinline__ uint32_t pair_off(uint2 z, int p) {
+    const uint32_t w = p < 4 ? z.x : z.y;
+    const int s = 8 * (p & 3);
+    return s == 0 ? (w << 3) & 0x7F8u : (w >> (s - 3)) & 0x7F8u;
+}
+
 // (w, n, b) wave-uniform: all index arithmetic is scalar, 32-bit (C * 64 fits an int, checked by the host)
 // SQ: f_state is the square copy [w][n][m][lane] (rows contiguous in m) instead of the edge-major state
 template <bool SQ>
 __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32, int mode,
-                                            uint32_t *__restrict__ f_r, int w, int n, int b, int lane) {
+                                            uint2 *__restrict__ f_S, int w, int n, int b, int lane) {
     const uint8_t *__restrict__ fw = SQ ? f_state + ((int64_t)w * Nreg + n) * Nreg * 64 : f_state + (int64_t)w * C32 * 64;
     const int tn = (n * (n - 1)) >> 1;
     const uint32_t sh = 8u * (uint32_t)(lane & 3);
@@ -79,28 +99,28 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
         // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
         k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
     }
-    uint32_t v = 0;
+    uint32_t v[2] = {0u, 0u};
 #pragma unroll
     for (int p = 0; p < R_NB / 2; ++p) {
         const int m0 = b * R_NB + 2 * p, m1 = m0 + 1;
         const uint32_t k0 = (m0 < Nreg && m0 != n) ? k[2 * p] : 0u;
         const uint32_t k1 = (m1 < Nreg && m1 != n) ? k[2 * p + 1] : 0u;
-        v |= (k0 * 3u + k1) << (4 * p);
+        v[p >> 2] |= ((k0 * 3u + k1) << 2) << (8 * (p & 3));
     }
-    f_r[(((int64_t)w * Nreg + n) * NBLK + b) * 64 + lane] = v;
+    f_S[(((int64_t)w * Nreg + n) * NBLK + b) * 64 + lane] = make_uint2(v[0], v[1]);
 }
 
 // grid (ceil(NBLK / 4), rows n0 .. n1-1, GW): one wave per (w, n, b), no index division
 template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
-                                                     int mode, uint32_t *__restrict__ f_r, int n0) {
+                                                     int mode, uint2 *__restrict__ f_S, int n0) {
     const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
-    pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_r, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
+    pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
 }
 
 __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
-                                                     uint16_t *__restrict__ r_T) {
+                                                     uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S) {
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: the index math stays off the VALU
     if (item >= GW * U * NBLK) return;
@@ -113,13 +133,7 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
         v |= (m < Nreg ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
     r_T[(int64_t)item * 64 + lane] = (uint16_t)v;
-}
-
-// f of region j of the block from the pair-coded word: field q = 3 k_even + k_odd
-__device__ inline uint32_t f_of(uint32_t word, int j) {
-    const uint32_t q = (word >> (4 * (j >> 1))) & 15u;
-    const uint32_t hi = (q * 11u) >> 5;          // q / 3 for q in 0..8
-    return (j & 1) ? q - 3u * hi : hi;
+    r_S[(int64_t)item * 64 + lane] = spread2(v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,9 +157,11 @@ __device__ inline uint32_t f_of(uint32_t word, int j) {
 // ---------------------------------------------------------------------------------------------
 struct r_step_args {
     const double *lMd, *hyper;
-    const uint32_t *f_r;
+    const uint2 *f_S;       // f pair bytes (q << 2)
     const uint16_t *r_T;    // r words before the pass (pack_r): what the blocks above the current one still hold
     uint16_t *r_Tn;         // r words redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
+    const uint2 *r_S;       // the same two, one byte per pair of regions (what the panel role reads)
+    uint2 *r_Sn;
     uint64_t *r_bits;
     double *Pbuf[2];        // e = (dpi + panel sum) - threshold: P(s) writes [s & 1], D(s) reads it
     uint32_t *flags;        // one-launch form: cntP[wg][uc][s] | cntD[wg][uc][s] | error word; else nullptr
@@ -208,7 +224,7 @@ __device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint
     return ok;
 }
 
-constexpr int P_GRP = 8;   // blocks of 16 regions whose state words are prefetched together
+constexpr int P_GRP = 4;   // blocks of 16 regions whose state words are prefetched together (24 VGPRs a group at 2 patients)
 // role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 36 entries <= 1024 threads
 constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
 constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
@@ -274,8 +290,8 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     FCD_TRACE(trec, 5);
     // wave-uniform bases (scalar registers) + unsigned 32-bit lane offsets: no per-lane 64-bit pointers
     const uint32_t ulane = (uint32_t)lane;
-    const uint32_t *__restrict__ fr = a.f_r + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64;
-    // r words: blocks above the current one from the old array, blocks below from the redrawn one
+    const uint2 *__restrict__ fr = a.f_S + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64;
+    // r bytes: blocks above the current one from the array made before the pass, blocks below from the redrawn one
     // (blocks st-1 and st are loaded with the rest but not used: they come from the old array too, so that no line of
     // the redrawn array is touched -- and cached -- before it is final)
     int64_t rt[UB];
@@ -284,19 +300,19 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
         const int uu = u < nu ? u : nu - 1;
         rt[u] = ((int64_t)(live ? w : 0) * U + u0 + uu) * NBLK * 64;
     }
-    const int64_t redrawn = a.r_Tn - a.r_T;          // element distance between the two arrays (wave-uniform select below)
-    auto rword = [&](int u, int b) -> uint32_t {
-        const uint16_t *base = a.r_T + (rt[u] + b * 64 + (b >= st - 1 ? (int64_t)0 : redrawn));
-        return (uint32_t)base[ulane] << 3;
+    const int64_t redrawn = a.r_Sn - a.r_S;          // element distance between the two arrays (wave-uniform select below)
+    auto rword = [&](int u, int b) -> uint2 {
+        const uint2 *base = a.r_S + (rt[u] + b * 64 + (b >= st - 1 ? (int64_t)0 : redrawn));
+        return base[ulane];
     };
     // state words of the first group of blocks: issued before the barriers, their latency hides behind the staging
-    uint32_t fpv[P_GRP], rwv[P_GRP][UB];
+    uint2 fpv[P_GRP], rwv[P_GRP][UB];
 #pragma unroll
     for (int g = 0; g < P_GRP; ++g) {
         const int b = (g < NBLK) ? g : NBLK - 1;
         fpv[g] = fr[b * 64 + ulane];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) rwv[g][u] = rword(u, b);   // tt*8 sits at bits 3..4 after >> 2p
+        for (int u = 0; u < UB; ++u) rwv[g][u] = rword(u, b);
     }
     __syncthreads();
     FCD_TRACE(trec, 1);
@@ -321,7 +337,10 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     __syncthreads();
     FCD_TRACE(trec, 2);
     if (!live) return true;
-    const char *pb = reinterpret_cast<const char *>(pairs);
+    // LDS byte offset of the tile: reads go through an LDS-space pointer so that (block base + pair, patient offset)
+    // becomes scalar base + instruction immediate
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
     double d[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
@@ -332,7 +351,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     // current group's terms run, so no global latency sits on the loop.
     for (int bg = 0; bg < NBLK; bg += P_GRP) {
         // (always loaded, from a clamped block index: a guard around each load turns into a branch and a wait per word)
-        uint32_t fpn[P_GRP], rwn[P_GRP][UB];
+        uint2 fpn[P_GRP], rwn[P_GRP][UB];
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
             const int b = (bg + P_GRP + g < NBLK) ? bg + P_GRP + g : NBLK - 1;
@@ -344,18 +363,15 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
         for (int g = 0; g < P_GRP; ++g) {
             const int b = bg + g;
             if (b >= NBLK || (b >= x0 && b < x1)) continue;
-            if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g] + rwv[g][0] + rwv[g][UB - 1]); continue; }   // ablation: loads only
-            const uint32_t fp = fpv[g];
-            const uint32_t base = (uint32_t)b * ((R_NB / 2) * REC);
+            if (FCD_ABL(1, 2)) { d[0] += (double)(fpv[g].x + rwv[g][0].y + rwv[g][UB - 1].x); continue; }   // ablation: loads only
+            const uint32_t base = pb_off + (uint32_t)b * ((R_NB / 2) * REC);
 #pragma unroll
-            for (int p = 0; p < R_NB / 2; ++p) {
-                // q picks the 32-byte (k, k') row of the pair record; bits 3..4 of the address are free for (t, t')
-                const uint32_t qb = (((fp >> (4 * p)) & 15u) << 5) + (base + (uint32_t)p * REC);
+            for (int u = 0; u < UB; ++u) {
+                // one byte per pair: (q << 2) | tt, i.e. the offset of the term inside its pair record, / 8
+                const uint2 z = make_uint2(fpv[g].x | rwv[g][u].x, fpv[g].y | rwv[g][u].y);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const uint32_t ad = ((rwv[g][u] >> (2 * p)) & 24u) | qb;
-                    d[u] += *reinterpret_cast<const double *>(pb + ad + (uint32_t)u * 288u);
-                }
+                for (int p = 0; p < R_NB / 2; ++p)
+                    d[u] += *(lds_cdouble *)(uintptr_t)(pair_off(z, p) + base + (uint32_t)p * REC + (uint32_t)u * 288u);
             }
         }
 #pragma unroll
@@ -418,7 +434,8 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
     const uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
     uint16_t *__restrict__ rTn = a.r_Tn + (wu * NBLK + b) * 64;
-    const uint32_t *__restrict__ frw = a.f_r + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
+    uint2 *__restrict__ rSn = a.r_Sn + (wu * NBLK + b) * 64;
+    const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
     const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
     __syncthreads();
     FCD_TRACE(trec, 1);
@@ -465,14 +482,14 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     const uint32_t rprev = hasA ? ld_h<COH>(rTn - 64 + ulane) << 3 : 0u;
     constexpr int PF_E = 4, PF_F = 2;
     double ev[PF_E];
-    uint32_t fa[PF_F], fb[PF_F];
+    uint2 fa[PF_F], fb[PF_F];
 #pragma unroll
     for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
 #pragma unroll
     for (int i = 0; i < PF_F - 1; ++i) {
-        const uint32_t *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
+        const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
         fb[i] = fro[ulane];
-        fa[i] = hasA ? (fro - 64)[ulane] : 0u;
+        fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
     }
     uint32_t rbv[R_NB / 2];
 #pragma unroll
@@ -484,19 +501,19 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
             {
                 const int ie = i + PF_E - 1, jf = i + PF_F - 1;
                 ev[ie % PF_E] = ld_d<COH>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
-                const uint32_t *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
+                const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
                 fb[jf % PF_F] = fro[ulane];
-                fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : 0u;
+                fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
             }
-            const uint32_t fwa = fa[i % PF_F], fwb = fb[i % PF_F];
+            const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
             double v = ev[i % PF_E];
-            if (FCD_ABL(2, 2)) { fresh |= (v + (double)(fwa + fwb) > 0.0 ? 1u : 0u) << i; continue; }
+            if (FCD_ABL(2, 2)) { fresh |= (v + (double)(fwa.x + fwb.y) > 0.0 ? 1u : 0u) << i; continue; }
             double sa, sb;
             {
                 double ta[R_NB / 2];
 #pragma unroll
                 for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t adA = (((fwa >> (4 * p)) & 15u) << 5) | ((rprev >> (2 * p)) & 24u);
+                    const uint32_t adA = pair_off(fwa, p) | ((rprev >> (2 * p)) & 24u);
                     ta[p] = *reinterpret_cast<const double *>(pa + adA + (uint32_t)((i * (R_NB / 2) + p) * 288));
                 }
                 sa = ((ta[0] + ta[1]) + (ta[2] + ta[3])) + ((ta[4] + ta[5]) + (ta[6] + ta[7]));
@@ -505,7 +522,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
                 double tb[R_NB / 2];
 #pragma unroll
                 for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t adB = (((fwb >> (4 * p)) & 15u) << 5) | rbv[p];
+                    const uint32_t adB = pair_off(fwb, p) | rbv[p];
                     tb[p] = *reinterpret_cast<const double *>(pa + adB + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
                 }
                 sb = ((tb[0] + tb[1]) + (tb[2] + tb[3])) + ((tb[4] + tb[5]) + (tb[6] + tb[7]));
@@ -526,6 +543,14 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
         }
     }
     st_h<COH>(rTn + ulane, (uint16_t)fresh);
+    {
+        // the same bits, one byte per pair, for the panel role (a 64-bit agent-scope store in the one-launch form)
+        const uint2 sp = spread2(fresh);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rSn + ulane);
+        const unsigned long long val = (unsigned long long)sp.x | ((unsigned long long)sp.y << 32);
+        if (COH) __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = val;
+    }
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
         if (i < nb) {
@@ -957,26 +982,32 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
             return FCD_OK;
         }
     }
-    // blocked path.  Workspace: P[2] | f_r | r_T | r_Tn | flags
+    // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
     const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
-    const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint32_t);
+    const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint2);
     const size_t r_bytes = ((size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
+    const size_t s_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint2);
     const int nWGs = (g.GW + 15) / 16;
     const size_t flag_words = (size_t)2 * nWGs * U * NBLK + 1;                   // (at most U chunks) + the error word
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX || (int64_t)g.GW * U * R_NB > INT32_MAX / 64)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, 2 * t_bytes + f_bytes + 2 * r_bytes + flag_words * sizeof(uint32_t) + 512);
+    rc = fcd_ws_reserve(ctx, 2 * t_bytes + f_bytes + 2 * r_bytes + 2 * s_bytes + flag_words * sizeof(uint32_t) + 512);
     if (rc) return rc;
-    double *Pb[2] = {(double *)ctx->ws, (double *)((char *)ctx->ws + t_bytes)};
-    uint32_t *f_r = (uint32_t *)((char *)ctx->ws + 2 * t_bytes);
-    uint16_t *r_T = (uint16_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes);
-    uint16_t *r_Tn = (uint16_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + r_bytes);
-    uint32_t *flags = (uint32_t *)((char *)ctx->ws + 2 * t_bytes + f_bytes + 2 * r_bytes);
+    char *wsp = (char *)ctx->ws;
+    double *Pb[2] = {(double *)wsp, (double *)(wsp + t_bytes)};
+    wsp += 2 * t_bytes;
+    uint2 *f_S = (uint2 *)wsp;
+    wsp += f_bytes;
+    uint2 *r_S = (uint2 *)wsp, *r_Sn = (uint2 *)(wsp + s_bytes);
+    wsp += 2 * s_bytes;
+    uint16_t *r_T = (uint16_t *)wsp, *r_Tn = (uint16_t *)(wsp + r_bytes);
+    wsp += 2 * r_bytes;
+    uint32_t *flags = (uint32_t *)wsp;
     {
         const int64_t items_r = (int64_t)g.GW * U * NBLK;
         hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
-                           g.GW, r_T);
+                           g.GW, r_T, r_S);
         FCD_LAUNCH_CHECK();
     }
     fcd_abl_refresh(s);
@@ -995,7 +1026,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         if (shmem < d_need) shmem = d_need;
     }
     r_step_args a;
-    a.lMd = lMd; a.hyper = hyper; a.f_r = f_r; a.r_T = r_T; a.r_Tn = r_Tn; a.r_bits = r_bits;
+    a.lMd = lMd; a.hyper = hyper; a.f_S = f_S; a.r_T = r_T; a.r_Tn = r_Tn; a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
     a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
     a.flags = nullptr;
     a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;
@@ -1014,10 +1045,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
     if (fsq)
         hipLaunchKernelGGL(pack_f_kernel<true>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
-                           fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
+                           fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, 0);
     else
         hipLaunchKernelGGL(pack_f_kernel<false>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
-                           f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_r, 0);
+                           f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, 0);
     FCD_LAUNCH_CHECK();
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
     // measured 472 us against 400 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
