@@ -4,21 +4,26 @@
 // and only d = s1 - s0 enters the draw:  r_nu = 1  <=>  logit(x) < d.
 //
 // The scan over n is a Gauss-Seidel sweep: r_n sees the NEW r_m for m < n and the OLD r_m for m > n.
-// It is organised like a blocked forward substitution.  Regions are cut into blocks of R_NB = 16; for a
-// block B every term with m outside B is already decided when B starts (new below B, old above B), so
-//   * the PANEL kernel computes, for every n in B, the sum over all m outside B -- fully parallel over
-//     (n, patient, chain); it streams the region-major rows lMd[u][n][:] (contiguous, staged in LDS and
-//     shared by all chain words of the workgroup), so the table is read once per pass;
-//   * the DIAGONAL kernel walks the 16 regions of B in order for each (patient, chain word), adding the
-//     few within-block terms from an LDS copy of the diagonal tile and drawing r_n; one wave per
-//     (patient, chain word), no barriers, no exp/division on the dependent chain.
-// 2 * ceil(Nreg / 16) launches per pass; >98 % of the arithmetic is in the panel kernels.
+// It is organised like a blocked forward substitution with a one-block look-ahead.  Regions are cut into blocks
+// of R_NB = 16; block step s does two independent things, in ONE launch (gibbs_r_step_kernel):
+//   * role P(s): for every n of block s, the sum over all m outside blocks s-1 and s -- new r below block s-1, old r
+//     above block s, all final before the launch starts; fully parallel over (n, patient, chain); the region-major
+//     rows lMd[u][n][:] are staged in LDS and shared by all chain words of the workgroup, so the table is read once
+//     per pass.  The same workgroups make the draw thresholds of their (region, patient pair) and store
+//     e = ln(pi/(1-pi)) + sum - logit(x);
+//   * role D(s-1): for each (patient, chain word) walk the 16 regions of block s-1 in order, adding to e the terms
+//     against block s-2 (redrawn by the previous launch) and against the own block from LDS copies of the two
+//     tiles, and draw r_n = [v > 0]; one wave per (patient, chain word), nothing but the 1-bit decision links one
+//     region to the next.
+// ceil(Nreg / 16) + 1 launches per pass; the serial part rides beside the parallel part of the next block.
+// gibbs_r_pass_kernel is the same pass in one launch (roles hand over through counters in device memory).
 //
 // lMd (U, Nreg, Nreg, 3, 2) is a region-major DIFFERENCE table made once per table build:
 //   lMd[u][n][m][k][t] = t ? lM[c,u,k,1] - lM[c,u,k,2] : lM[c,u,k,2] - lM[c,u,k,0],   c = edge(n, m)
 // i.e. the contribution of region m to d for f_c = k and r_mu = t; edge() is the SAME ordered-pair edge id
 // the reference uses (fit.py:186 calls nm_to_c(n, m) for every ordered pair in 'reference' mode), so that
-// quirk is baked into the table.  One term = one 8-byte LDS read + one fp64 add.
+// quirk is baked into the table.  One term (a PAIR of regions, see the pair records below) = one 8-byte LDS read
+// + one fp64 add + two integer instructions.
 #include <stdlib.h>
 
 #include "fcd_common.h"
