@@ -513,45 +513,57 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const uint8_t *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 3, wrow = lane >> 2;          // 16-byte piece of the 64-byte row, chain word within a group of 16
     unsigned long long tot1 = 0, tot2 = 0, n_edges = 0;
-    for (int64_t c = (int64_t)blockIdx.x * 16 + wave; c < C; c += (int64_t)gridDim.x * 16) {
-        uint32_t ones = 0, twos = 0;
+    // Four edges per round, their loads issued together: the pass is a few memory round trips long, what counts is
+    // the number of bytes in flight (one 16-byte load per lane and round left the memory side at ~1.4 TB/s).
+    constexpr int TE = 4;
+    for (int64_t c0 = ((int64_t)blockIdx.x * 16 + wave) * TE; c0 < C; c0 += (int64_t)gridDim.x * 16 * TE) {
         for (int wg = 0; wg < GW; wg += 16) {
             const int w = wg + wrow;
-            if (w < GW) {
-                uint4 v = *reinterpret_cast<const uint4 *>(f_state + ((int64_t)w * C + c) * 64 + sub * 16);
-                const uint32_t act = (uint32_t)(fcd_active_mask(w, G) >> (sub * 16)) & 0xFFFFu;
-                if (act != 0xFFFFu) {   // last, partial chain word: drop the bytes of chains that do not exist
+            uint4 vv[TE];
+#pragma unroll
+            for (int t = 0; t < TE; ++t) {
+                const int64_t c = (c0 + t < C) ? c0 + t : C - 1;
+                vv[t] = *reinterpret_cast<const uint4 *>(f_state + ((int64_t)(w < GW ? w : 0) * C + c) * 64 + sub * 16);
+            }
+            const uint32_t act = (w < GW) ? (uint32_t)(fcd_active_mask(w, G) >> (sub * 16)) & 0xFFFFu : 0u;
+#pragma unroll
+            for (int t = 0; t < TE; ++t) {
+                uint4 v = vv[t];
+                if (act != 0xFFFFu) {   // partial (or absent) chain word: drop the bytes of chains that do not exist
                     v.x &= (((act & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
                     v.y &= ((((act >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
                     v.z &= ((((act >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
                     v.w &= ((((act >> 12) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
                 }
-                ones += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
-                        __popc(v.w & 0x01010101u);
-                twos += __popc((v.x >> 1) & 0x01010101u) + __popc((v.y >> 1) & 0x01010101u) +
-                        __popc((v.z >> 1) & 0x01010101u) + __popc((v.w >> 1) & 0x01010101u);
+                uint32_t ones = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+                                __popc(v.w & 0x01010101u);
+                uint32_t twos = __popc((v.x >> 1) & 0x01010101u) + __popc((v.y >> 1) & 0x01010101u) +
+                                __popc((v.z >> 1) & 0x01010101u) + __popc((v.w >> 1) & 0x01010101u);
+                for (int o = 32; o > 0; o >>= 1) {
+                    ones += __shfl_xor(ones, o, 64);
+                    twos += __shfl_xor(twos, o, 64);
+                }
+                if (lane == 0 && c0 + t < C) {
+                    const int64_t c = c0 + t;
+                    if (cnt_f) {
+                        // (atomics because they do not wait for the old value to come back)
+                        atomicAdd(&cnt_f[c * 3 + 1], ones);
+                        atomicAdd(&cnt_f[c * 3 + 2], twos);
+                        if (wg == 0) atomicAdd(&cnt_f[c * 3 + 0], (uint32_t)G);
+                        atomicAdd(&cnt_f[c * 3 + 0], 0u - ones - twos);
+                    }
+                    tot1 += ones;
+                    tot2 += twos;
+                    if (wg == 0) n_edges += 1;
+                }
             }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            ones += __shfl_xor(ones, o, 64);
-            twos += __shfl_xor(twos, o, 64);
-        }
-        if (lane == 0) {
-            if (cnt_f) {
-                cnt_f[c * 3 + 0] += (uint32_t)G - ones - twos;
-                cnt_f[c * 3 + 1] += ones;
-                cnt_f[c * 3 + 2] += twos;
-            }
-            tot1 += ones;
-            tot2 += twos;
-            n_edges += 1;
         }
     }
     unsigned long long cr = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NU; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t sr = 0;
         for (int w = 0; w < GW; ++w) sr += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
-        if (cnt_r) cnt_r[i] += sr;
+        if (cnt_r) atomicAdd(&cnt_r[i], sr);
         cr += sr;
     }
     if (counts) {
@@ -849,15 +861,18 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
     if (ctx && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 &&
         f_step_writes_sq(lMf, Nreg, U, (G + 63) / 64)) {
         const size_t need = (size_t)((G + 63) / 64) * Nreg * Nreg * 64;
-        if (need > ctx->fsq_bytes) {
+        if (need > ctx->fsq_bytes && need <= ((size_t)8 << 30)) {
             FCD_HIP_TRY(hipDeviceSynchronize());
             if (ctx->fsq) FCD_HIP_TRY(hipFree(ctx->fsq));
             ctx->fsq = nullptr;
             ctx->fsq_bytes = 0;
-            FCD_HIP_TRY(hipMalloc(&ctx->fsq, need));
-            ctx->fsq_bytes = need;
+            if (hipMalloc(&ctx->fsq, need) == hipSuccess) ctx->fsq_bytes = need;
+            else {
+                ctx->fsq = nullptr;           // an optimisation only: carry on without the copy
+                (void)hipGetLastError();
+            }
         }
-        fsq = (uint8_t *)ctx->fsq;
+        if (need <= ctx->fsq_bytes) fsq = (uint8_t *)ctx->fsq;
     }
     for (int64_t i = 0; i < n_sweeps; ++i) {
         int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,
@@ -906,7 +921,7 @@ extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     if (!counts && !cnt_f) return FCD_OK;
     hipStream_t s = (hipStream_t)stream;
     if (counts) FCD_HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), s));
-    int64_t blocks = (g.C + 15) / 16;
+    int64_t blocks = (g.C + 63) / 64;          // 16 waves x 4 edges per workgroup and round
     const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, f_state, r_bits, g.C, Nreg * U, g.GW, G,
