@@ -115,21 +115,9 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
     f_S[(((int64_t)w * Nreg + n) * NBLK + b) * 64 + lane] = make_uint2(v[0], v[1]);
 }
 
-// grid (ceil(NBLK / 4), rows n0 .. n1-1, GW): one wave per (w, n, b), no index division
-template <bool SQ>
-__global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
-                                                     int mode, uint2 *__restrict__ f_S, int n0) {
-    const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (b >= NBLK) return;
-    pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, n0 + (int)blockIdx.y, b, (int)(threadIdx.x & 63));
-}
-
-__global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK, int GW,
-                                                     uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S) {
-    const int lane = threadIdx.x & 63;
-    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: the index math stays off the VALU
-    if (item >= GW * U * NBLK) return;
-    const int b = item % NBLK, u = (item / NBLK) % U, w = item / (NBLK * U);
+// r words of (w, u, b): bit j = r_{16 b + j, u}, and the same bits one byte per pair of regions
+__device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK,
+                                            uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S, int w, int u, int b, int lane) {
     uint32_t v = 0;
 #pragma unroll
     for (int j = 0; j < R_NB; ++j) {
@@ -137,8 +125,22 @@ __global__ __launch_bounds__(256) void pack_r_kernel(const uint64_t *__restrict_
         const uint64_t word = r_bits[((int64_t)w * Nreg + (m < Nreg ? m : Nreg - 1)) * U + u];    // clamped: no branch per load
         v |= (m < Nreg ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
-    r_T[(int64_t)item * 64 + lane] = (uint16_t)v;
-    r_S[(int64_t)item * 64 + lane] = spread2(v);
+    const int64_t o = (((int64_t)w * U + u) * NBLK + b) * 64 + lane;
+    r_T[o] = (uint16_t)v;
+    r_S[o] = spread2(v);
+}
+
+// grid (ceil(NBLK / 4), Nreg + U, GW): one wave per (w, n, b) resp. (w, u, b), no index division.
+// y < Nreg: f words of region n = y;  y >= Nreg: r words of patient u = y - Nreg (r_bits == nullptr: f words only).
+template <bool SQ>
+__global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
+                                                     int mode, uint2 *__restrict__ f_S, const uint64_t *__restrict__ r_bits,
+                                                     int U, uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S) {
+    const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (b >= NBLK) return;
+    const int y = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
+    if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane);
+    else pack_r_item(r_bits, Nreg, U, NBLK, r_T, r_S, (int)blockIdx.z, y - Nreg, b, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -934,7 +936,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
     hipStream_t s = (hipStream_t)stream;
     const size_t per_u_need = ((size_t)((Nreg + R_NB - 1) / R_NB) * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
-    if (!lMd || per_u_need > 156 * 1024 || U > 65535) {
+    if (!lMd || per_u_need > 156 * 1024 || Nreg + U > 65535) {
         // generic path: direct gathers from the edge-major table
         const size_t shmem = (size_t)Nreg * 8 + (size_t)R_WAVES * 2 * 64 * 8;
         if (shmem > 64 * 1024) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld exceeds the LDS mask array", Nreg);
@@ -1009,12 +1011,6 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     uint16_t *r_T = (uint16_t *)wsp, *r_Tn = (uint16_t *)(wsp + r_bytes);
     wsp += 2 * r_bytes;
     uint32_t *flags = (uint32_t *)wsp;
-    {
-        const int64_t items_r = (int64_t)g.GW * U * NBLK;
-        hipLaunchKernelGGL(pack_r_kernel, dim3((unsigned)((items_r + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NBLK,
-                           g.GW, r_T, r_S);
-        FCD_LAUNCH_CHECK();
-    }
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
     const size_t per_u = ((size_t)NBLK * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
@@ -1048,13 +1044,17 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     const int nUC = (int)((U + ub - 1) / ub);
     int persist = 0;
     if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
-    if (fsq)
-        hipLaunchKernelGGL(pack_f_kernel<true>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
-                           fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, 0);
-    else
-        hipLaunchKernelGGL(pack_f_kernel<false>, dim3((unsigned)((NBLK + 3) / 4), (unsigned)Nreg, (unsigned)g.GW), dim3(256), 0, s,
-                           f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, 0);
-    FCD_LAUNCH_CHECK();
+    {
+        // one launch packs the f words of every region and the r words of every patient
+        dim3 pgrid((unsigned)((NBLK + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
+        if (fsq)
+            hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
+                               (int)U, r_T, r_S);
+        else
+            hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
+                               r_bits, (int)U, r_T, r_S);
+        FCD_LAUNCH_CHECK();
+    }
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
     // measured 472 us against 400 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
     // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the
