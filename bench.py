@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+LDS_CLOCK_GHZ = 2.4          # MI355X peak engine clock
+LDS_BYTES_PER_CLK_CU = 256   # profiles/r01_ubench_lds_fp64.txt: 250 B/clk/CU with ds_read_b128 (8-byte reads top out at ~180)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
 
 
@@ -170,6 +172,19 @@ def main():
         except Exception:
             traffic = None
 
+    # What actually bounds the two sweep kernels (DESIGN.md section e): wave-wide LDS reads.  Bytes the LDS serves per
+    # launch (64 lanes x 8 or 16 bytes per read, counted from the loop structure) against the measured LDS peak.
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    lds_peak = n_cu * LDS_BYTES_PER_CLK_CU * LDS_CLOCK_GHZ / 1e3                                   # TB/s
+    nblk = (Nreg + 15) // 16
+    gw = (G + 63) // 64
+    f_lds = C * gw * ((U + 1) // 2) * 64 * 16                                     # one ds_read_b128 per (edge, word, patient pair)
+    r_lds_pass = gw * U * Nreg * nblk * 8 * 64 * 8                                # one ds_read_b64 per (region, patient, word, pair of regions)
+    lds = {"unit": "TB/s", "peak": lds_peak,
+           "gibbs_f_pair_kernel": f_lds / (kern["gibbs_f_pair_kernel"]["avg_launch_ms"] * 1e-3) / 1e12,
+           "gibbs_r_step_kernel": r_lds_pass / n_step / (kern["gibbs_r_step_kernel"]["avg_launch_ms"] * 1e-3) / 1e12}
+    lds["frac"] = {k: lds[k] / lds_peak for k in ("gibbs_f_pair_kernel", "gibbs_r_step_kernel")}
+
     out = {
         "metric": "posterior samples/sec at R=200 ROIs, N=100 subj, 1024 chains; 1/2/4/8 GPUs",
         "value": world * G * args.steps / elapsed,
@@ -196,6 +211,7 @@ def main():
                              "are shared by all chains and stay in L2 / Infinity Cache at this size, so the sweep is bound by "
                              "wave-wide LDS reads, not by HBM (DESIGN.md section e, profiles/r01_ubench_lds_fp64.txt)"},
         "kernels": kern,
+        "lds_roofline": lds,
         "passes_ms": {"f_pass": f_pass_ms, "r_pass": r_pass_ms,
                       "f_pass_GBps": f_bytes / (f_pass_ms * 1e-3) / 1e9, "r_pass_GBps": r_bytes / (r_pass_ms * 1e-3) / 1e9,
                       "f64_adds_per_s": (2 * C * U * G + 2 * C * U * G) / ((f_pass_ms + r_pass_ms) * 1e-3)},
