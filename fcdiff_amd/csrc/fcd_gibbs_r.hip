@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
 //   pr[q = 3k + k'][tt = t + 2t'] = lMd[u][n][m][k][t] + lMd[u][n][m+1][k'][t']              (288 bytes)
 // built in LDS from the two single rows while staging.  One 8-byte LDS read and one fp64 add then cover
 // TWO regions; the address is  q*32 + tt*8  from the packed f / r words (2 integer ops per term + 2 per pair).
-// LDS: pairs [8*NBLK][UB][36] doubles + singles [UB][Nreg*6] doubles (scratch).
+// LDS: pairs [8*NBLK][UB][36] doubles + singles [UB][16*NBLK*6] doubles (scratch, zero beyond Nreg).
 // ---------------------------------------------------------------------------------------------
 struct r_step_args {
     const double *lMd, *hyper;
@@ -248,7 +248,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     const int nUC = (U + UB - 1) / UB;
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
-    double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][Nreg*6]
+    double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][16 NBLK regions * 6], zero beyond Nreg
     const int n = st * R_NB + row;
     const int u0 = uc * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
@@ -258,12 +258,14 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     FCD_TRACE_VAL(trec, 6, 1);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
     {
-        const int row_d2 = Nreg * 3;
+        // rows padded with zero records to a whole number of blocks: the pair build below needs no guards
+        const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3;
         double2 *dst = reinterpret_cast<double2 *>(single);
-        for (int it = threadIdx.x; it < UB * row_d2; it += blockDim.x) {
-            const int u = it / row_d2, i = it - u * row_d2;
+        for (int it = threadIdx.x; it < UB * pad_d2; it += blockDim.x) {
+            const int u = it / pad_d2, i = it - u * pad_d2;
             const int us = u < nu ? u : nu - 1;            // tail chunk: replicate the last patient (never stored)
-            dst[it] = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i];
+            dst[it] = i < row_d2 ? reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i]
+                                 : make_double2(0.0, 0.0);
         }
     }
     const int lane = threadIdx.x & 63;
@@ -331,13 +333,10 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
         const int k = q / 3, k2 = q - 3 * k;
         const int o0 = k * 2 + (tt & 1), o1 = k2 * 2 + (tt >> 1);
         if ((int)threadIdx.x < step * 36) {
+            const int pad6 = NBLK * R_NB * 6;
             for (int pu = threadIdx.x / 36; pu < n_pairs * UB; pu += step) {
-                const int u = pu % UB, m = 2 * (pu / UB);
-                const double *su = single + u * Nreg * 6 + m * 6;
-                double v = 0.0;
-                if (m < Nreg) v = su[o0];
-                if (m + 1 < Nreg) v += su[6 + o1];
-                pairs[pu * 36 + e] = v;
+                const double *su = single + (pu % UB) * pad6 + (pu / UB) * 12;      // pair (m, m+1), m = 2 (pu / UB)
+                pairs[pu * 36 + e] = su[o0] + su[6 + o1];
             }
         }
     }
@@ -935,7 +934,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
         return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
     hipStream_t s = (hipStream_t)stream;
-    const size_t per_u_need = ((size_t)((Nreg + R_NB - 1) / R_NB) * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
+    const size_t per_u_need = (size_t)((Nreg + R_NB - 1) / R_NB) * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
     if (!lMd || per_u_need > 156 * 1024 || Nreg + U > 65535) {
         // generic path: direct gathers from the edge-major table
         const size_t shmem = (size_t)Nreg * 8 + (size_t)R_WAVES * 2 * 64 * 8;
@@ -1013,7 +1012,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     uint32_t *flags = (uint32_t *)wsp;
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
-    const size_t per_u = ((size_t)NBLK * (R_NB / 2) * 36 + (size_t)Nreg * 6) * sizeof(double);
+    const size_t per_u = (size_t)NBLK * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
     // (2 patients: two workgroups fit a CU, whose staging / pair-build / term phases then overlap; measured best at cfg3)
     int ub = 1;
     while (ub < 2 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
