@@ -73,6 +73,22 @@ def test_error_strings_and_state_size():
     assert lib.fcd_gibbs_state_size(1, 50, 64, C.byref(fb), C.byref(rb)) == _lib.FCD_ERR_ARG
 
 
+def test_error_codes_of_header_and_binding_agree():
+    """Every FCD_ERR_* of include/fcdiff_hip.h has the same value in the binding and a message of its own."""
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fcdiff_hip.h")).read()
+    codes = dict(re.findall(r"#define (FCD_ERR_[A-Z]+) \((-\d+)\)", text))
+    assert set(codes) == {"FCD_ERR_ARG", "FCD_ERR_SHAPE", "FCD_ERR_UNSUPPORTED", "FCD_ERR_INDEX", "FCD_ERR_DEVICE"}
+    lib = _lib.load()
+    seen = set()
+    for (name, val) in codes.items():
+        assert getattr(_lib, name) == int(val)
+        msg = lib.fcd_strerror(int(val))
+        assert msg and msg != b"unknown fcdiff_hip error" and msg not in seen
+        seen.add(msg)
+
+
 def test_fitter_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
