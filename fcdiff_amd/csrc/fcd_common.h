@@ -123,6 +123,10 @@ __host__ __device__ static inline double fcd_u53(uint32_t hi, uint32_t lo) {
     return (double)(w >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// One 32-bit word as a double in [0, 1): what the 3-way f draws of the sweeps use (four edges per counter block).
+__host__ __device__ static inline double fcd_u32(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+__host__ __device__ static inline uint32_t fcd_word(const fcd_u4 &x, int i) { return i == 0 ? x.x : i == 1 ? x.y : i == 2 ? x.z : x.w; }
+
 __host__ __device__ static inline double fcd_site_uniform(uint64_t seed, uint32_t idx, uint32_t chain,
                                                           uint32_t sweep, uint32_t kind, int half) {
     fcd_u4 x = fcd_philox(idx, chain, sweep, kind, (uint32_t)seed, (uint32_t)(seed >> 32));

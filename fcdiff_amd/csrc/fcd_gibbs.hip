@@ -127,11 +127,11 @@ __global__ __launch_bounds__(1024) void gibbs_f_kernel(const double *__restrict_
                 o[0] = a0; o[1] = a1; o[2] = a2;
             }
         } else {
-            if ((c >> 1) != rnd_idx) {
-                rnd_idx = c >> 1;
+            if ((c >> 2) != rnd_idx) {
+                rnd_idx = c >> 2;
                 rnd = fcd_philox((uint32_t)rnd_idx, chain, sweep, FCD_KIND_F, k0, k1);
             }
-            const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
             f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)fcd_draw_f(a0, a1, a2, x);
         }
     }
@@ -216,11 +216,11 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
             f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
             continue;
         }
-        if ((c >> 1) != rnd_idx) {
-            rnd_idx = c >> 1;
+        if ((c >> 2) != rnd_idx) {
+            rnd_idx = c >> 2;
             rnd = fcd_philox((uint32_t)rnd_idx, chain, sweep, FCD_KIND_F, k0, k1);
         }
-        const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+        const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
         bool amb;
         int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
         if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);      // too close to a boundary somewhere in the wave
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
                 continue;
             }
-            if ((e & 1) == 0) rnd = fcd_philox((uint32_t)(c >> 1), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is even
-            const double x = (c & 1) ? fcd_u53(rnd.z, rnd.w) : fcd_u53(rnd.x, rnd.y);
+            if ((e & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is a multiple of 8
+            const double x = fcd_u32(fcd_word(rnd, e & 3));
             bool amb;
             int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
             if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave

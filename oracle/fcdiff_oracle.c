@@ -206,6 +206,13 @@ static inline double site_uniform(uint64_t seed, uint32_t idx, uint32_t chain, u
     return half ? u53(x[2], x[3]) : u53(x[0], x[1]);
 }
 
+/* sweeps of f: one counter block per four edges, one 32-bit word each */
+static inline double site_uniform32(uint64_t seed, uint32_t idx, uint32_t chain, uint32_t sweep, uint32_t kind, int word) {
+    uint32_t x[4];
+    philox(idx, chain, sweep, kind, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    return (double)x[word] * (1.0 / 4294967296.0);
+}
+
 enum { KIND_INIT_F = 0, KIND_INIT_R = 1, KIND_F = 2, KIND_R = 3 };
 
 /* ------------------------------------------------------------------ Gibbs */
@@ -257,8 +264,8 @@ void oracle_gibbs_f_step(uint8_t *f, const uint8_t *r, const double *S_B, const 
             for (int k = 0; k < 3; ++k) a[k] = lngamma[k] + (S_B[c * 3 + k] + a[k]);
             if (cond) memcpy(cond + (g * C + c) * 3, a, sizeof(a));
             if (draw)
-                f[g * C + c] = (uint8_t)draw_f(a[0], a[1], a[2], site_uniform(seed, (uint32_t)(c >> 1), (uint32_t)(chain0 + g),
-                                                                              (uint32_t)sweep, KIND_F, (int)(c & 1)));
+                f[g * C + c] = (uint8_t)draw_f(a[0], a[1], a[2], site_uniform32(seed, (uint32_t)(c >> 2), (uint32_t)(chain0 + g),
+                                                                                (uint32_t)sweep, KIND_F, (int)(c & 3)));
         }
     }
 }

@@ -462,7 +462,19 @@ def site_uniform(seed, idx, chain, sweep, kind, half):
 
 
 def f_site(c):
+    """initial state: one counter block per two edges, 53-bit uniforms"""
     return (c >> 1, c & 1)
+
+
+def f_draw_site(c):
+    """sweeps: one counter block per FOUR edges, one 32-bit word each (a 3-way draw does not need 53 bits)"""
+    return (c >> 2, c & 3)
+
+
+def site_uniform32(seed, idx, chain, sweep, kind, word):
+    """The double in [0,1) a site draws from ONE word of philox(ctr=(idx, chain, sweep, kind), key=seed): word * 2^-32."""
+    x = philox4x32_10((idx, chain, sweep, kind), (seed & _M32, (seed >> 32) & _M32))
+    return x[word] * (1.0 / 4294967296.0)
 
 
 def r_site(n, u, U):
@@ -556,8 +568,8 @@ def gibbs_f_step(f, r, S_B, lM, lngamma, seed, sweep, chain0=0):
     for g in range(G):
         for c in range(C):
             a = f_conditional_logits(c, r[g], S_B, lM, lngamma)
-            (idx, half) = f_site(c)
-            f[g, c] = draw_f(a, site_uniform(seed, idx, chain0 + g, sweep, KIND_F, half))
+            (idx, word) = f_draw_site(c)
+            f[g, c] = draw_f(a, site_uniform32(seed, idx, chain0 + g, sweep, KIND_F, word))
 
 
 def gibbs_r_step(f, r, lM, lnpi2, seed, sweep, mode=EDGE_SYMMETRIC, chain0=0):
