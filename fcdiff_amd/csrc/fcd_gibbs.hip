@@ -260,7 +260,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
                                                             int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin, uint8_t *__restrict__ fsq) {
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
+    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
+    double *tile = ptile;
     const int NPAIR = (U + 1) >> 1;
     const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
     const int ne = (int)((C - c0 < FP_EC) ? (C - c0) : FP_EC);
@@ -333,6 +334,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
     const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
+    typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
+    typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
+    const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ptile;   // 256-aligned
     int sq_n, sq_m;                      // (n, m) of the edge at hand (wave-uniform walk)
     fcd_edge_to_pair(c0, sq_n, sq_m);
 
@@ -340,26 +344,30 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     for (int e = 0; e < FP_EC; ++e) {
         if (e < ne) {
             const int64_t c = c0 + e;
-            const char *tb = reinterpret_cast<const char *>(tile) + (int64_t)e * NPAIR * 256;
+            // LDS byte offset of the edge's records (scalar, a multiple of 256: the tile is 256-aligned)
+            const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 256));
             double b1 = 0.0, b2 = 0.0;
 #pragma unroll
             for (int g = 0; g < NW16; ++g) {
                 if (g < NG) {
                     const uint32_t zs = Z[e][g];
-                    const char *gb = tb + g * (8 * 256);
+                    const uint32_t gb = tb + (uint32_t)(g * (8 * 256));
                     if (NPAIR - 8 * g >= 8) {
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
-                            // slot -> 16-byte records: byte offset = slot << 4
-                            const uint32_t off = (p == 0) ? ((zs << 4) & 0xF0u) : ((zs >> (4 * p - 4)) & 0xF0u);
-                            const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                            // slot -> 16-byte records: byte offset = slot << 4, OR-ed into the (256-aligned) group base in
+                            // one instruction; the pair offset p * 256 is the read's immediate
+                            const uint32_t sh = (p == 0) ? (zs << 4) : (zs >> (4 * p - 4));
+                            uint32_t ad;
+                            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0xF0u), "v"(gb));   // (one SGPR per VOP3)
+                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(p * 256));
                             b1 += v.x;
                             b2 += v.y;
                         }
                     } else {
                         for (int p = 0; p < NPAIR - 8 * g; ++p) {
                             const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
-                            const double2 v = *reinterpret_cast<const double2 *>(gb + p * 256 + off);
+                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + gb + (uint32_t)(p * 256));
                             b1 += v.x;
                             b2 += v.y;
                         }
