@@ -278,17 +278,19 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     // Consecutive edges c = n(n-1)/2 + m share n: its words are fetched once per run, not once per edge.
     uint32_t Z[FP_EC][NW16];      // slot numbers (x_u, x_u+1, a_u, a_u+1) of 8 pairs of patients per word
     if (w < GW) {
-        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW16 * 64 + lane;
+        // wave-uniform base + unsigned 32-bit (region, lane) offset: no per-lane 64-bit address arithmetic
+        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW16 * 64;
+        const uint32_t ul = (uint32_t)lane;
         int n, m;
         fcd_edge_to_pair(c0, n, m);
         uint32_t rn[NW16];
 #pragma unroll
-        for (int j = 0; j < NW16; ++j) rn[j] = ru[(int64_t)(n * NW16 + j) * 64];
+        for (int j = 0; j < NW16; ++j) rn[j] = ru[(uint32_t)((n * NW16 + j) * 64) + ul];
 #pragma unroll
         for (int e = 0; e < FP_EC; ++e) {
 #pragma unroll
             for (int j = 0; j < NW16; ++j) {
-                const uint32_t rm = ru[(int64_t)(m * NW16 + j) * 64];
+                const uint32_t rm = ru[(uint32_t)((m * NW16 + j) * 64) + ul];
                 Z[e][j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
             }
             // next edge of the lower-triangular order: (n, m+1), or (n+1, 0) at the end of row n
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 m = 0;
                 n = (n + 1 < Nreg) ? n + 1 : n;       // past the last edge only for e >= ne (unused)
 #pragma unroll
-                for (int j = 0; j < NW16; ++j) rn[j] = ru[(int64_t)(n * NW16 + j) * 64];
+                for (int j = 0; j < NW16; ++j) rn[j] = ru[(uint32_t)((n * NW16 + j) * 64) + ul];
             }
         }
     }
@@ -309,8 +311,15 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
         const bool valid = !((x0 & a0) | (x1 & a1));
         const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
         const int total = ne * NPAIR;
-        for (int ep = threadIdx.x >> 4; ep < total; ep += blockDim.x >> 4) {
-            const int e = ep / NPAIR, pr = ep - e * NPAIR;
+        // (edge, pair) of record ep, stepped without an integer division per turn
+        const int stride = blockDim.x >> 4;
+        const int sq_ = stride / NPAIR, sr_ = stride - sq_ * NPAIR;
+        int e = (int)(threadIdx.x >> 4) / NPAIR, pr = (int)(threadIdx.x >> 4) - e * NPAIR;
+        for (int ep = threadIdx.x >> 4; ep < total; ep += stride, e += sq_, pr += sr_) {
+            if (pr >= NPAIR) {
+                pr -= NPAIR;
+                ++e;
+            }
             const int u = 2 * pr;
             double2 v = make_double2(0.0, 0.0);
             if (valid) {
