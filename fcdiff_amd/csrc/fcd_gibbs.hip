@@ -394,12 +394,12 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             bool amb;
             int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
             if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
-            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)k;
+            (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
             if (fsq) {
                 // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
-                uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64 + lane;
-                sq[((int64_t)sq_n * Nreg + sq_m) * 64] = (uint8_t)k;
-                sq[((int64_t)sq_m * Nreg + sq_n) * 64] = (uint8_t)k;
+                uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
+                (sq + ((int64_t)sq_n * Nreg + sq_m) * 64)[(uint32_t)lane] = (uint8_t)k;
+                (sq + ((int64_t)sq_m * Nreg + sq_n) * 64)[(uint32_t)lane] = (uint8_t)k;
             }
         }
         if (++sq_m == sq_n) {     // next edge of the lower-triangular order
