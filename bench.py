@@ -155,7 +155,6 @@ def main():
     # algorithmic bytes, SURVEY.md section 8d (u8 state): lM once per pass + state
     f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
     r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
-    kern.pop("gibbs_r_diag", None)                                                # (slot unused: the in-order part rides in the step kernel)
     n_step = max(kern["gibbs_r_step_kernel"]["launches"] // max(args.steps, 1), 1)   # step launches per pass
     per_launch_bytes = {"gibbs_f_pair_kernel": f_bytes,
                         # a step launch serves 16 of the Nreg regions' rows of the r pass

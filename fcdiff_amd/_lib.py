@@ -149,7 +149,7 @@ class Context(object):
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args), self.handle)
 
-    PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "gibbs_r_diag": 3}
+    PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "pack_f_kernel": 3}
 
     def prof_enable(self, on=True):
         self.call("fcd_prof_enable", 1 if on else 0)

@@ -10,8 +10,8 @@
 #define FCD_PROF_SLOTS 4
 #define FCD_PROF_LIK 0
 #define FCD_PROF_F 1
-#define FCD_PROF_PANEL 2
-#define FCD_PROF_DIAG 3
+#define FCD_PROF_RSTEP 2
+#define FCD_PROF_PACK 3
 
 struct fcd_ctx {
     int device;

@@ -868,9 +868,9 @@ int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
     }
-    fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
+    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
     hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(64 * a.wpb), shmem, s, a);
-    fcd_prof_end(ctx, FCD_PROF_PANEL, s);
+    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -887,9 +887,9 @@ int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool
     if (e != hipSuccess) return (int)e;
     *fits = (int64_t)per_cu * ctx->num_cu >= grid;      // every workgroup resident at once, or no one-launch form
     if (!*fits) return FCD_OK;
-    fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
+    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
     hipLaunchKernelGGL((gibbs_r_pass_kernel<UB, WPE>), dim3((unsigned)grid), dim3(64 * a.wpb), shmem, s, a);
-    fcd_prof_end(ctx, FCD_PROF_PANEL, s);
+    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -976,14 +976,14 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
             FCD_LAUNCH_CHECK();
             const int WB = 16 / MSsel;
             dim3 grid((unsigned)U, (unsigned)((g.GW + WB - 1) / WB));
-            fcd_prof_begin(ctx, FCD_PROF_PANEL, s);
+            fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
             if (MSsel == 8)
                 hipLaunchKernelGGL(gibbs_r_seq_kernel<8>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
                                    (int)U, g.GW);
             else
                 hipLaunchKernelGGL(gibbs_r_seq_kernel<16>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
                                    (int)U, g.GW);
-            fcd_prof_end(ctx, FCD_PROF_PANEL, s);
+            fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
             FCD_LAUNCH_CHECK();
             return FCD_OK;
         }
@@ -1046,12 +1046,14 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     {
         // one launch packs the f words of every region and the r words of every patient
         dim3 pgrid((unsigned)((NBLK + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
+        fcd_prof_begin(ctx, FCD_PROF_PACK, s);
         if (fsq)
             hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
                                (int)U, r_T, r_S);
         else
             hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
                                r_bits, (int)U, r_T, r_S);
+        fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:

@@ -68,7 +68,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 
 /* Optional timing of the library's main kernels with HIP events recorded on the launch stream, each pair
- * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r panel, 3 r diagonal.
+ * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r block step (or one-launch pass), 3 r pack.
  * fcd_prof_collect waits for the recorded events, returns the summed milliseconds and the number of
  * launches, and clears the slot.  Off by default (no events are recorded). */
 int fcd_prof_enable(fcd_ctx *ctx, int on);
