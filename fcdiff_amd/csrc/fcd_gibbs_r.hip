@@ -88,21 +88,36 @@ __device__ __forceinline__ uint32_t pair_off(uint2 z, int p) {
 // SQ: f_state is the square copy [w][n][m][lane] (rows contiguous in m) instead of the edge-major state
 template <bool SQ>
 __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32, int mode,
-                                            uint2 *__restrict__ f_S, int w, int n, int b, int lane) {
+                                            uint2 *__restrict__ f_S, int w, int n, int b, int lane,
+                                            uint8_t *__restrict__ lds_wave) {
     const uint8_t *__restrict__ fw = SQ ? f_state + ((int64_t)w * Nreg + n) * Nreg * 64 : f_state + (int64_t)w * C32 * 64;
     const int tn = (n * (n - 1)) >> 1;
     const uint32_t sh = 8u * (uint32_t)(lane & 3);
     // all 16 loads first (from a clamped, always valid edge: a guard around a load is a branch and a wait per load),
     // the regions that do not exist or are n itself are masked afterwards
     uint32_t k[R_NB];
+    if (SQ) {
+        // The 16 regions of the block are ONE contiguous kilobyte of the square copy: a single 16-byte load per lane
+        // fetches it (lane L: region L/4, chains 16 (L%4) ..), the wave's LDS slice turns it round (region j, chain
+        // lane = byte j*64 + lane).  One memory instruction instead of 16.
+        const int ml = b * R_NB + (lane >> 2);
+        const uint4 q = *reinterpret_cast<const uint4 *>(fw + (uint32_t)((ml < Nreg ? ml : 0) * 64 + (lane & 3) * 16));
+        *reinterpret_cast<uint4 *>(lds_wave + lane * 16) = q;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int j = 0; j < R_NB; ++j) {
-        const int m = b * R_NB + j;
-        const bool on = m < Nreg && m != n;
-        const int mm = on ? m : (n > 0 ? 0 : 1);
-        const int e = SQ ? mm : (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
-        // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
-        k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
+        for (int j = 0; j < R_NB; ++j) k[j] = lds_wave[j * 64 + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < R_NB; ++j) {
+            const int m = b * R_NB + j;
+            const bool on = m < Nreg && m != n;
+            const int mm = on ? m : (n > 0 ? 0 : 1);
+            const int e = (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
+            // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
+            k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
+        }
     }
     uint32_t v[2] = {0u, 0u};
 #pragma unroll
@@ -139,7 +154,8 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
     const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
     const int y = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
-    if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane);
+    __shared__ __attribute__((aligned(16))) uint8_t turn[4][R_NB * 64];      // one kilobyte per wave (square-copy form)
+    if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane, turn[threadIdx.x >> 6]);
     else pack_r_item(r_bits, Nreg, U, NBLK, r_T, r_S, (int)blockIdx.z, y - Nreg, b, lane);
 }
 
