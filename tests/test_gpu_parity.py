@@ -442,6 +442,31 @@ def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
     nptest.assert_array_equal(r_g, r_o)
 
 
+@pytest.mark.gpu
+def test_gibbs_sweeps_driver_equals_separate_passes(env):
+    """
+    fcd_gibbs_sweeps (the f pass leaves a square copy of the f state, the r pass packs from it) and the two passes
+    called one by one (the r pass gathers from the edge-major state) walk the same chains: 3 sweeps, several blocks
+    of regions, a partial chain word.
+    """
+    (N, U, G) = (45, 7, 200)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=21)
+    states = []
+    for fused in (True, False):
+        eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=8, seed=77, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.25)
+        for s in range(3):
+            if fused:
+                eng.sweeps(s, 1)
+            else:
+                eng.f_step(s)
+                eng.r_step(s)
+        states.append(eng.export_state())
+    nptest.assert_array_equal(states[0][0], states[1][0])
+    nptest.assert_array_equal(states[0][1], states[1][1])
+
+
 def test_gibbs_chain_sharding_invariance(env):
     """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
     (N, U, G) = (12, 6, 192)
