@@ -443,6 +443,31 @@ def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,U,G,mode", [(17, 1, 64, "symmetric"), (16, 2, 70, "symmetric"), (32, 3, 2048, "symmetric"),
+                                        (250, 4, 64, "symmetric"), (33, 7, 1100, "reference"), (3, 2, 64, "symmetric"),
+                                        (48, 66, 64, "symmetric"), (100, 17, 1024, "symmetric")])
+def test_gibbs_sweeps_odd_shapes(env, N, U, G, mode):
+    """
+    Corners of the sweep kernels against the C oracle, two sweeps each: one patient, exactly one block of regions,
+    more than 16 chain words (two word groups), 16 blocks of regions, a partial chain word with the reference edge
+    ids, three regions, more than 64 patients (the U > 64 form of the f pass), an odd number of patients at 1024 chains.
+    """
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=3, seed=5, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, 5, 3)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for s in range(2):
+        eng.sweeps(s, 1)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, 5, s, 3)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, 5, s, env.lib.EDGE_MODES[mode], 3)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
+@pytest.mark.gpu
 def test_gibbs_sweeps_driver_equals_separate_passes(env):
     """
     fcd_gibbs_sweeps (the f pass leaves a square copy of the f state, the r pass packs from it) and the two passes
