@@ -67,7 +67,17 @@ __global__ __launch_bounds__(256) void vb_qF_kernel(const double *__restrict__ l
 // One workgroup per patient u (patients are independent given q_F); regions strictly in order with
 // q_R[n] refreshed before region n+1 (Gauss-Seidel, fit.py:184-197).  Threads split the m-sum.
 constexpr int QR_BLOCK = 256;
-__global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restrict__ lq_F, const double *__restrict__ lM,
+// q_F = exp(lq_F), once per call (fit.py:180 takes the exponential once, too)
+__global__ __launch_bounds__(256) void vb_expF_kernel(const double *__restrict__ lq_F, int64_t n, double *__restrict__ qF) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) qF[i] = exp(lq_F[i]);
+}
+
+// One block per patient (patients are independent), regions strictly in order (Gauss-Seidel, fit.py:184-197), the
+// threads split the sum over m.  The operands of region n+1 (its 9 table values and 3 q_F per thread and m) do not
+// depend on what region n decides: they are requested before region n is reduced, so the scattered 72-byte table
+// reads (one memory round trip, ~2 us) hide behind the reduction instead of adding up 200 times.
+template <int MPT>   // regions m per thread: Nreg <= MPT * QR_BLOCK
+__global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restrict__ qF, const double *__restrict__ lM,
                                                          const double *__restrict__ hyper, int Nreg, int U, int mode,
                                                          double *__restrict__ lq_R) {
     extern __shared__ double sh[];
@@ -80,24 +90,46 @@ __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restric
         q0[n] = exp(lq_R[((int64_t)n * U + u) * 2 + 0]);
         q1[n] = exp(lq_R[((int64_t)n * U + u) * 2 + 1]);
     }
+    struct Op {
+        double p[9], f[3];
+        bool on;
+    };
+    auto load = [&](int n, Op (&o)[MPT]) {
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            const int m = tid + j * QR_BLOCK;
+            o[j].on = m < Nreg && m != n;
+            const int64_t c = o[j].on ? fcd_pair_to_edge(n, m, mode) : 0;
+            const double *p = lM + (c * U + u) * 9;
+#pragma unroll
+            for (int x = 0; x < 9; ++x) o[j].p[x] = p[x];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[j].f[k] = qF[c * 3 + k];
+        }
+    };
+    // three operand buffers: region n is computed from one while region n+2 is on its way into another
+    Op bufA[MPT], bufB[MPT], bufC[MPT];
+    load(0, bufA);
+    if (Nreg > 1) load(1, bufB);
     __syncthreads();
     const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
-    for (int n = 0; n < Nreg; ++n) {
+    auto step = [&](int n, Op (&cur)[MPT], Op (&fill)[MPT]) {
+        if (n + 2 < Nreg) load(n + 2, fill);
         double t0 = 0.0, t1 = 0.0;
-        for (int m = tid; m < Nreg; m += QR_BLOCK) {
-            if (m == n) continue;
-            const int64_t c = fcd_pair_to_edge(n, m, mode);
-            const double *p = lM + (c * U + u) * 9;
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            if (!cur[j].on) continue;
+            const int m = tid + j * QR_BLOCK;
             const double qm0 = q0[m], qm1 = q1[m];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double qF = exp(lq_F[c * 3 + k]);
-                const double lM_00 = qm0 * p[k * 3 + 0];
-                const double lM_1neq = qm1 * p[k * 3 + 2];
-                t0 += qF * (lM_00 + lM_1neq);          // fit.py:188-190
-                const double lM_11 = qm1 * p[k * 3 + 1];
-                const double lM_0neq = qm0 * p[k * 3 + 2];
-                t1 += qF * (lM_11 + lM_0neq);          // fit.py:192-194
+                const double qFk = cur[j].f[k];
+                const double lM_00 = qm0 * cur[j].p[k * 3 + 0];
+                const double lM_1neq = qm1 * cur[j].p[k * 3 + 2];
+                t0 += qFk * (lM_00 + lM_1neq);         // fit.py:188-190
+                const double lM_11 = qm1 * cur[j].p[k * 3 + 1];
+                const double lM_0neq = qm0 * cur[j].p[k * 3 + 2];
+                t1 += qFk * (lM_11 + lM_0neq);         // fit.py:192-194
             }
         }
         t0 = fcd_wave_sum(t0);
@@ -107,21 +139,24 @@ __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restric
             red[(tid >> 6) * 2 + 1] = t1;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 2) {
+            // (two lanes: both form the normaliser, each finishes its own state -- one exp on the serial path, not two)
             double s0 = lnpi0, s1 = lnpi1;
             for (int w = 0; w < QR_BLOCK / 64; ++w) {
                 s0 += red[w * 2 + 0];
                 s1 += red[w * 2 + 1];
             }
             const double z = lse2(s0, s1);             // fit.py:196
-            s0 -= z;
-            s1 -= z;
-            lq_R[((int64_t)n * U + u) * 2 + 0] = s0;
-            lq_R[((int64_t)n * U + u) * 2 + 1] = s1;
-            q0[n] = exp(s0);                           // fit.py:197
-            q1[n] = exp(s1);
+            const double mine = (tid == 0 ? s0 : s1) - z;
+            lq_R[((int64_t)n * U + u) * 2 + tid] = mine;
+            (tid == 0 ? q0 : q1)[n] = exp(mine);       // fit.py:197
         }
         __syncthreads();
+    };
+    for (int n = 0; n < Nreg; n += 3) {
+        step(n, bufA, bufC);
+        if (n + 1 < Nreg) step(n + 1, bufB, bufA);
+        if (n + 2 < Nreg) step(n + 2, bufC, bufB);
     }
 }
 
@@ -273,9 +308,22 @@ extern "C" int fcd_vb_update_qR(fcd_ctx *ctx, const double *lq_F, const double *
     if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
         return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
     const size_t shmem = (size_t)(2 * Nreg + 2 * (QR_BLOCK / 64)) * sizeof(double);
-    if (shmem > 160 * 1024) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_vb_update_qR: Nreg=%lld exceeds LDS", Nreg);
-    hipLaunchKernelGGL(vb_qR_kernel, dim3((unsigned)U), dim3(QR_BLOCK), shmem, (hipStream_t)stream, lq_F, lM, hyper,
-                       (int)Nreg, (int)U, edge_mode, lq_R);
+    if (shmem > 160 * 1024 || Nreg > 4 * QR_BLOCK)
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_vb_update_qR: Nreg=%lld exceeds LDS / 4 regions per thread", Nreg);
+    const int64_t nF = fcd_tri(Nreg) * 3;
+    rc = fcd_ws_reserve(ctx, (size_t)nF * sizeof(double));
+    if (rc) return rc;
+    double *qF = (double *)ctx->ws;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vb_expF_kernel, dim3((unsigned)((nF + 255) / 256 < 1024 ? (nF + 255) / 256 : 1024)), dim3(256), 0, s, lq_F, nF, qF);
+    FCD_LAUNCH_CHECK();
+    const int mpt = (int)((Nreg + QR_BLOCK - 1) / QR_BLOCK);
+    if (mpt <= 1)
+        hipLaunchKernelGGL(vb_qR_kernel<1>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+    else if (mpt == 2)
+        hipLaunchKernelGGL(vb_qR_kernel<2>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+    else
+        hipLaunchKernelGGL(vb_qR_kernel<4>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
