@@ -80,15 +80,17 @@ template <int MPT>   // regions m per thread: Nreg <= MPT * QR_BLOCK
 __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restrict__ qF, const double *__restrict__ lM,
                                                          const double *__restrict__ hyper, int Nreg, int U, int mode,
                                                          double *__restrict__ lq_R) {
-    extern __shared__ double sh[];
-    double *q0 = sh;             // [Nreg]
-    double *q1 = sh + Nreg;      // [Nreg]
-    double *red = sh + 2 * Nreg; // [2 * QR_BLOCK/64]
+    __shared__ double red[2][2 * (QR_BLOCK / 64)];      // wave partials, double-buffered: one barrier per region
     const int u = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int n = tid; n < Nreg; n += QR_BLOCK) {
-        q0[n] = exp(lq_R[((int64_t)n * U + u) * 2 + 0]);
-        q1[n] = exp(lq_R[((int64_t)n * U + u) * 2 + 1]);
+    // q of the thread's own regions m = tid + j * QR_BLOCK lives in registers; every thread finishes every region
+    // itself (same arithmetic in all lanes), so nothing but the wave partials crosses threads
+    double q0m[MPT], q1m[MPT];
+#pragma unroll
+    for (int j = 0; j < MPT; ++j) {
+        const int m = tid + j * QR_BLOCK;
+        q0m[j] = m < Nreg ? exp(lq_R[((int64_t)m * U + u) * 2 + 0]) : 0.0;
+        q1m[j] = m < Nreg ? exp(lq_R[((int64_t)m * U + u) * 2 + 1]) : 0.0;
     }
     struct Op {
         double p[9], f[3];
@@ -111,7 +113,6 @@ __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restric
     Op bufA[MPT], bufB[MPT], bufC[MPT];
     load(0, bufA);
     if (Nreg > 1) load(1, bufB);
-    __syncthreads();
     const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
     auto step = [&](int n, Op (&cur)[MPT], Op (&fill)[MPT]) {
         if (n + 2 < Nreg) load(n + 2, fill);
@@ -119,8 +120,7 @@ __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restric
 #pragma unroll
         for (int j = 0; j < MPT; ++j) {
             if (!cur[j].on) continue;
-            const int m = tid + j * QR_BLOCK;
-            const double qm0 = q0[m], qm1 = q1[m];
+            const double qm0 = q0m[j], qm1 = q1m[j];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double qFk = cur[j].f[k];
@@ -134,24 +134,29 @@ __global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restric
         }
         t0 = fcd_wave_sum(t0);
         t1 = fcd_wave_sum(t1);
+        double *rb = red[n & 1];
         if ((tid & 63) == 0) {
-            red[(tid >> 6) * 2 + 0] = t0;
-            red[(tid >> 6) * 2 + 1] = t1;
+            rb[(tid >> 6) * 2 + 0] = t0;
+            rb[(tid >> 6) * 2 + 1] = t1;
         }
         __syncthreads();
-        if (tid < 2) {
-            // (two lanes: both form the normaliser, each finishes its own state -- one exp on the serial path, not two)
-            double s0 = lnpi0, s1 = lnpi1;
-            for (int w = 0; w < QR_BLOCK / 64; ++w) {
-                s0 += red[w * 2 + 0];
-                s1 += red[w * 2 + 1];
+        double s0 = lnpi0, s1 = lnpi1;
+        for (int w = 0; w < QR_BLOCK / 64; ++w) {
+            s0 += rb[w * 2 + 0];
+            s1 += rb[w * 2 + 1];
+        }
+        const double z = lse2(s0, s1);                 // fit.py:196
+        s0 -= z;
+        s1 -= z;
+        if (tid < 2) lq_R[((int64_t)n * U + u) * 2 + tid] = tid == 0 ? s0 : s1;
+        const double e0 = exp(s0), e1 = exp(s1);       // fit.py:197
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            if (tid + j * QR_BLOCK == n) {
+                q0m[j] = e0;
+                q1m[j] = e1;
             }
-            const double z = lse2(s0, s1);             // fit.py:196
-            const double mine = (tid == 0 ? s0 : s1) - z;
-            lq_R[((int64_t)n * U + u) * 2 + tid] = mine;
-            (tid == 0 ? q0 : q1)[n] = exp(mine);       // fit.py:197
         }
-        __syncthreads();
     };
     for (int n = 0; n < Nreg; n += 3) {
         step(n, bufA, bufC);
@@ -307,9 +312,9 @@ extern "C" int fcd_vb_update_qR(fcd_ctx *ctx, const double *lq_F, const double *
         return fcd_fail(ctx, FCD_ERR_ARG, "fcd_vb_update_qR: edge_mode %lld", edge_mode);
     if (edge_mode == FCD_EDGE_REFERENCE && Nreg == 2)
         return fcd_fail(ctx, FCD_ERR_INDEX, "reference edge ids: index 1 is out of bounds for axis 0 with size 1 (Nreg=2)");
-    const size_t shmem = (size_t)(2 * Nreg + 2 * (QR_BLOCK / 64)) * sizeof(double);
-    if (shmem > 160 * 1024 || Nreg > 4 * QR_BLOCK)
-        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_vb_update_qR: Nreg=%lld exceeds LDS / 4 regions per thread", Nreg);
+    const size_t shmem = 0;
+    if (Nreg > 4 * QR_BLOCK)
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_vb_update_qR: Nreg=%lld exceeds 4 regions per thread", Nreg);
     const int64_t nF = fcd_tri(Nreg) * 3;
     rc = fcd_ws_reserve(ctx, (size_t)nF * sizeof(double));
     if (rc) return rc;
