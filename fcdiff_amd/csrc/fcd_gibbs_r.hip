@@ -247,7 +247,8 @@ __device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint
     return ok;
 }
 
-constexpr int P_GRP = 4;   // blocks of 16 regions whose state words are prefetched together (24 VGPRs a group at 2 patients)
+constexpr int P_GRP = 2;   // blocks of 16 regions whose state words are prefetched together: 12 VGPRs a group at 2 patients
+                           // (measured at cfg3: 1 -> 326 us per pass, 2 -> 316, 3 -> 322, 4 -> 352: register pressure)
 // role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 36 entries <= 1024 threads
 constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
 constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
