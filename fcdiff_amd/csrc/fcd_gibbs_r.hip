@@ -503,7 +503,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     const uint32_t ulane = (uint32_t)lane;
     const uint32_t rold = rTw[ulane];
     const uint32_t rprev = hasA ? ld_h<COH>(rTn - 64 + ulane) << 3 : 0u;
-    constexpr int PF_E = 4, PF_F = 2;
+    constexpr int PF_E = 3, PF_F = 2;
     double ev[PF_E];
     uint2 fa[PF_F], fb[PF_F];
 #pragma unroll
