@@ -266,12 +266,6 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
     const int ne = (int)((C - c0 < FP_EC) ? (C - c0) : FP_EC);
     double2 *single = reinterpret_cast<double2 *>(tile) + (size_t)FP_EC * NPAIR * 16;
-    {
-        // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
-        const int n_d2 = ne * U * 3;
-        const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
-        for (int i = threadIdx.x; i < n_d2; i += blockDim.x) single[i] = src[i];
-    }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
@@ -301,6 +295,12 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 for (int j = 0; j < NW16; ++j) rn[j] = ru[(uint32_t)((n * NW16 + j) * 64) + ul];
             }
         }
+    }
+    {
+        // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
+        const int n_d2 = ne * U * 3;
+        const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        for (int i = threadIdx.x; i < n_d2; i += blockDim.x) single[i] = src[i];
     }
     __syncthreads();
     {
