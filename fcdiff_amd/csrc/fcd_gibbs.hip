@@ -270,31 +270,19 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
     // Consecutive edges c = n(n-1)/2 + m share n: its words are fetched once per run, not once per edge.
-    uint32_t Z[FP_EC][NW16];      // slot numbers (x_u, x_u+1, a_u, a_u+1) of 8 pairs of patients per word
-    if (w < GW) {
-        // wave-uniform base + unsigned 32-bit (region, lane) offset: no per-lane 64-bit address arithmetic
-        const uint32_t *__restrict__ ru = r_U + (int64_t)w * Nreg * NW16 * 64;
-        const uint32_t ul = (uint32_t)lane;
-        int n, m;
-        fcd_edge_to_pair(c0, n, m);
-        uint32_t rn[NW16];
+    // Slot numbers (x_u, x_u+1, a_u, a_u+1) of 8 pairs of patients per word, for the edge at hand only: the words of
+    // the NEXT edge are requested while this edge's terms run (32 registers less than holding all 8 edges' words).
+    uint32_t Zc[NW16], rn[NW16];
+    int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
+    fcd_edge_to_pair(c0, wn, wm);
+    // wave-uniform base + unsigned 32-bit (region, lane) offset: no per-lane 64-bit address arithmetic
+    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * NW16 * 64;
+    const uint32_t ul = (uint32_t)lane;
 #pragma unroll
-        for (int j = 0; j < NW16; ++j) rn[j] = ru[(uint32_t)((n * NW16 + j) * 64) + ul];
-#pragma unroll
-        for (int e = 0; e < FP_EC; ++e) {
-#pragma unroll
-            for (int j = 0; j < NW16; ++j) {
-                const uint32_t rm = ru[(uint32_t)((m * NW16 + j) * 64) + ul];
-                Z[e][j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
-            }
-            // next edge of the lower-triangular order: (n, m+1), or (n+1, 0) at the end of row n
-            if (++m == n) {
-                m = 0;
-                n = (n + 1 < Nreg) ? n + 1 : n;       // past the last edge only for e >= ne (unused)
-#pragma unroll
-                for (int j = 0; j < NW16; ++j) rn[j] = ru[(uint32_t)((n * NW16 + j) * 64) + ul];
-            }
-        }
+    for (int j = 0; j < NW16; ++j) {
+        rn[j] = ru[(uint32_t)((wn * NW16 + j) * 64) + ul];
+        const uint32_t rm = ru[(uint32_t)((wm * NW16 + j) * 64) + ul];
+        Zc[j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
     }
     {
         // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
@@ -346,20 +334,32 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
     typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
     const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ptile;   // 256-aligned
-    int sq_n, sq_m;                      // (n, m) of the edge at hand (wave-uniform walk)
-    fcd_edge_to_pair(c0, sq_n, sq_m);
 
 #pragma unroll
     for (int e = 0; e < FP_EC; ++e) {
         if (e < ne) {
             const int64_t c = c0 + e;
+            // next edge: (n, m+1), or (n+1, 0) at the end of row n (clamped past the last edge: unused there)
+            int nn = wn, nm = wm + 1;
+            if (nm == nn) {
+                nm = 0;
+                nn = (nn + 1 < Nreg) ? nn + 1 : nn;
+            }
+            uint32_t rnn[NW16], rmn[NW16];
+            if (e + 1 < FP_EC) {
+#pragma unroll
+                for (int j = 0; j < NW16; ++j) {
+                    rnn[j] = ru[(uint32_t)((nn * NW16 + j) * 64) + ul];
+                    rmn[j] = ru[(uint32_t)((nm * NW16 + j) * 64) + ul];
+                }
+            }
             // LDS byte offset of the edge's records (scalar, a multiple of 256: the tile is 256-aligned)
             const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 256));
             double b1 = 0.0, b2 = 0.0;
 #pragma unroll
             for (int g = 0; g < NW16; ++g) {
                 if (g < NG) {
-                    const uint32_t zs = Z[e][g];
+                    const uint32_t zs = Zc[g];
                     const uint32_t gb = tb + (uint32_t)(g * (8 * 256));
                     if (NPAIR - 8 * g >= 8) {
 #pragma unroll
@@ -398,13 +398,18 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             if (fsq) {
                 // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
                 uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
-                (sq + ((int64_t)sq_n * Nreg + sq_m) * 64)[(uint32_t)lane] = (uint8_t)k;
-                (sq + ((int64_t)sq_m * Nreg + sq_n) * 64)[(uint32_t)lane] = (uint8_t)k;
+                (sq + ((int64_t)wn * Nreg + wm) * 64)[(uint32_t)lane] = (uint8_t)k;
+                (sq + ((int64_t)wm * Nreg + wn) * 64)[(uint32_t)lane] = (uint8_t)k;
             }
-        }
-        if (++sq_m == sq_n) {     // next edge of the lower-triangular order
-            sq_m = 0;
-            ++sq_n;
+            if (e + 1 < FP_EC) {
+#pragma unroll
+                for (int j = 0; j < NW16; ++j) {
+                    rn[j] = rnn[j];
+                    Zc[j] = (rnn[j] ^ rmn[j]) | ((rnn[j] & rmn[j]) << 2);
+                }
+                wn = nn;
+                wm = nm;
+            }
         }
     }
 }
