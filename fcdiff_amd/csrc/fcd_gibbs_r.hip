@@ -344,16 +344,20 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     FCD_TRACE(trec, 1);
     if (FCD_ABL(1, 4)) return true;       // ablation: single rows staged, no pair records
     {
-        // pair records: each thread keeps one of the 36 (q, tt) entries and walks the (pair, patient) list
-        const int e = threadIdx.x % 36, step = blockDim.x / 36;
-        const int q = e >> 2, tt = e & 3;
+        // pair records: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries from two 16-byte
+        // reads -- [k][t = 0, 1] of region m and [k'][t' = 0, 1] of region m+1 -- and two 16-byte writes: a third of the
+        // LDS instructions of one entry per thread, and two turns through the (pair, patient) list instead of seven
+        const int q = threadIdx.x % 9, step = blockDim.x / 9;
         const int k = q / 3, k2 = q - 3 * k;
-        const int o0 = k * 2 + (tt & 1), o1 = k2 * 2 + (tt >> 1);
-        if ((int)threadIdx.x < step * 36) {
+        if ((int)threadIdx.x < step * 9) {
             const int pad6 = NBLK * R_NB * 6;
-            for (int pu = threadIdx.x / 36; pu < n_pairs * UB; pu += step) {
+            for (int pu = threadIdx.x / 9; pu < n_pairs * UB; pu += step) {
                 const double *su = single + (pu % UB) * pad6 + (pu / UB) * 12;      // pair (m, m+1), m = 2 (pu / UB)
-                pairs[pu * 36 + e] = su[o0] + su[6 + o1];
+                const double2 a2 = *reinterpret_cast<const double2 *>(su + 2 * k);          // region m:   t  = 0, 1
+                const double2 b2 = *reinterpret_cast<const double2 *>(su + 6 + 2 * k2);     // region m+1: t' = 0, 1
+                double2 *dst = reinterpret_cast<double2 *>(pairs + pu * 36 + q * 4);        // tt = t + 2 t'
+                dst[0] = make_double2(a2.x + b2.x, a2.y + b2.x);
+                dst[1] = make_double2(a2.x + b2.y, a2.y + b2.y);
             }
         }
     }
