@@ -249,7 +249,7 @@ __device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint
 
 constexpr int P_GRP = 2;   // blocks of 16 regions whose state words are prefetched together: 12 VGPRs a group at 2 patients
                            // (measured at cfg3: 1 -> 326 us per pass, 2 -> 316, 3 -> 322, 4 -> 352: register pressure)
-// role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 36 entries <= 1024 threads
+// role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 9 rows of entries <= 1024 threads
 constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
 constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
 
@@ -467,26 +467,44 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     __syncthreads();
     FCD_TRACE(trec, 1);
     {
-        // pair records: each thread keeps one of the 36 (q, tt) entries; record (i, p) <- singles (i*16 + 2p) * 6
-        const int e = threadIdx.x % 36, step = blockDim.x / 36;
-        const int q = e >> 2, tt = e & 3;
+        // pair records, as in the panel role: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries
+        // with 16-byte reads and writes; record (i, p) <- singles (i*16 + 2p) * 6
+        const int q = threadIdx.x % 9, step = blockDim.x / 9;
         const int k = q / 3, k2 = q - 3 * k;
-        const int o0 = k * 2 + (tt & 1), o1 = k2 * 2 + (tt >> 1);
-        const int r0 = threadIdx.x / 36;
-        const bool on = (int)threadIdx.x < step * 36;
+        const int r0 = threadIdx.x / 9;
+        const bool on = (int)threadIdx.x < step * 9;
+        auto four = [&](const double *single_tile, int rec, double2 &lo, double2 &hi) {
+            const double2 a2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 2 * k);
+            const double2 b2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 6 + 2 * k2);
+            lo = make_double2(a2.x + b2.x, a2.y + b2.x);
+            hi = make_double2(a2.x + b2.y, a2.y + b2.y);
+        };
+        auto put = [&](int rec_abs, const double2 &lo, const double2 &hi) {
+            double2 *dst = reinterpret_cast<double2 *>(pairs + rec_abs * 36 + q * 4);
+            dst[0] = lo;
+            dst[1] = hi;
+        };
         if (on)
-            for (int rec = r0; rec < D_RECS_T; rec += step) pairs[rec * 36 + e] = sA[rec * 12 + o0] + sA[rec * 12 + 6 + o1];
+            for (int rec = r0; rec < D_RECS_T; rec += step) {
+                double2 lo, hi;
+                four(sA, rec, lo, hi);
+                put(rec, lo, hi);
+            }
         __syncthreads();                                  // single A is free: tile 1 may overwrite it
         const int safe = compact ? D_SAFE : D_RECS_T;
         if (on)
-            for (int rec = r0; rec < safe; rec += step)
-                pairs[(D_RECS_T + rec) * 36 + e] = sB[rec * 12 + o0] + sB[rec * 12 + 6 + o1];
-        if (compact) {                                    // the records single B sits on: one entry per thread
+            for (int rec = r0; rec < safe; rec += step) {
+                double2 lo, hi;
+                four(sB, rec, lo, hi);
+                put(D_RECS_T + rec, lo, hi);
+            }
+        if (compact) {                                    // the records single B sits on: one row of entries per thread
             const int rec = D_SAFE + r0;
             const bool mine = on && rec < D_RECS_T;
-            const double v = mine ? sB[rec * 12 + o0] + sB[rec * 12 + 6 + o1] : 0.0;
+            double2 lo = make_double2(0.0, 0.0), hi = lo;
+            if (mine) four(sB, rec, lo, hi);
             __syncthreads();
-            if (mine) pairs[(D_RECS_T + rec) * 36 + e] = v;
+            if (mine) put(D_RECS_T + rec, lo, hi);
         }
     }
     __syncthreads();
