@@ -1096,7 +1096,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         FCD_LAUNCH_CHECK();
     }
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
-    // measured 401 us against 310 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
+    // measured 348 us against 301 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
     // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the
     // hand-over adds waits), see DESIGN.md.
     if (persist) {
