@@ -1121,7 +1121,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         a.s = st;
         a.nD = st >= 1 ? (int)U * a.nWG : 0;
         a.nP = rows * nUC * a.nWG;
-        a.npad = (a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+        a.npad = (getenv("FCD_R_NOPAD") == nullptr && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
         if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s);
         else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s);
         else rc = launch_step<1, 8>(ctx, a, shmem, s);

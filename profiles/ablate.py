@@ -35,7 +35,7 @@ def main():
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
     cases = [("f full", "f", {}), ("f no-draw", "f", {"FCD_ABL_F": "2"}), ("f staging-only", "f", {"FCD_ABL_F": "3"}),
-             ("r full", "r", {}), ("r full, one-launch form", "r", {"FCD_R_PERSIST": "1"}), ("r full, one patient per panel workgroup", "r", {"FCD_R_UB": "1"}),
+             ("r full", "r", {}), ("r full, one-launch form", "r", {"FCD_R_PERSIST": "1"}), ("r full, one patient per panel workgroup", "r", {"FCD_R_UB": "1"}), ("r full, no empty workgroups beside D", "r", {"FCD_R_NOPAD": "1"}),
              ("r panel loads-only", "r", {"FCD_ABL_PANEL": "2"}), ("r panel staging-only", "r", {"FCD_ABL_PANEL": "3"}),
              ("r panel single rows only", "r", {"FCD_ABL_PANEL": "4"}), ("r panel empty", "r", {"FCD_ABL_PANEL": "5"}),
              ("r diag no next-thresholds", "r", {"FCD_ABL_DIAG": "1"}), ("r diag empty", "r", {"FCD_ABL_DIAG": "5"}),
@@ -45,7 +45,7 @@ def main():
     res = {name: [] for (name, _, _) in cases}
     for rnd in range(5):
         for (name, which, env) in cases:
-            for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG", "FCD_R_PERSIST", "FCD_R_UB"):
+            for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG", "FCD_R_PERSIST", "FCD_R_UB", "FCD_R_NOPAD"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             fn = eng.f_step if which == "f" else eng.r_step
