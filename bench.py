@@ -74,6 +74,15 @@ def main():
     C = fcdiff_amd.N_to_C(Nreg)
     chain0 = rank * G
     seed = 20240601
+    # which BASELINE.json config this is (configs[2] = "cfg3" is the one the metric is quoted on)
+    if (Nreg, H, U, G) == (200, 50, 50, 1024):
+        cfg_name = "cfg3" if world == 1 else "cfg4-style (cfg3 per GPU, %d GPUs)" % world
+    elif (Nreg, H, U, G) == (400, 250, 250, 1024):
+        cfg_name = "cfg5 per-GPU share (1024 of the 8192 chains)"
+    elif (Nreg, H, U, G) == (64, 16, 16, 256):
+        cfg_name = "cfg2"
+    else:
+        cfg_name = "custom"
 
     model = fcdiff_amd.UnsharedRegionModel()
     (_r, _t, _f, _ft, b, bt) = model.sample_fast(Nreg, H, U, seed=0)     # same data on every rank
@@ -197,8 +206,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "cfg3: Nreg=%d (C=%d edges), H=U=%d, %d chains/GPU, collapsed Gibbs sweep + pooled "
-                               "(pi,gamma) M-step every %d sweep(s), fixed tables" % (Nreg, C, U, G, args.mstep_every),
+        "config": {"workload": "%s: Nreg=%d (C=%d edges), H=%d, U=%d, %d chains/GPU, collapsed Gibbs sweep + pooled "
+                               "(pi,gamma) M-step every %d sweep(s), fixed tables" % (cfg_name, Nreg, C, H, U, G, args.mstep_every),
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

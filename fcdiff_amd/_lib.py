@@ -36,6 +36,8 @@ SIGNATURES = {
     "fcd_ctx_create": (_int, [C.POINTER(_p)]),
     "fcd_ctx_destroy": (_int, [_p]),
     "fcd_ctx_reserve": (_int, [_p, _i64, _i64, _i64]),
+    "fcd_ctx_set_knob": (_int, [_p, C.c_char_p, _dbl]),
+    "fcd_ctx_stat": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "fcd_prof_enable": (_int, [_p, _int]),
     "fcd_prof_collect": (_int, [_p, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     "fcd_N_to_C": (_i64, [_i64]),
@@ -148,6 +150,15 @@ class Context(object):
 
     def call(self, name, *args):
         check(getattr(self.lib, name)(self.handle, *args), self.handle)
+
+    def set_knob(self, name, value):
+        """Tuning / test knob of include/fcdiff_hip.h (fcd_ctx_set_knob); 0 restores the default."""
+        self.call("fcd_ctx_set_knob", name.encode(), float(value))
+
+    def stat(self, name):
+        v = _i64()
+        self.call("fcd_ctx_stat", name.encode(), C.byref(v))
+        return v.value
 
     PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "pack_f_kernel": 3}
 

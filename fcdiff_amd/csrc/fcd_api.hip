@@ -1,10 +1,10 @@
 // Context, error strings and the host-side index maps of libfcdiff_hip.so.
 #include <new>
+#include <stdlib.h>
 
 #include "fcd_common.h"
 
 #ifdef FCD_ABLATE
-#include <stdlib.h>
 __device__ int fcd_abl_level[4];
 __device__ unsigned long long *fcd_trace_buf;
 void fcd_abl_refresh(hipStream_t s) {
@@ -29,7 +29,32 @@ int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes) {
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
     FCD_HIP_TRY(hipMalloc(&ctx->ws, want));
     ctx->ws_bytes = want;
+    ctx->n_alloc += 1;
     return FCD_OK;
+}
+
+int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->fsq_bytes) return FCD_OK;
+    FCD_HIP_TRY(hipDeviceSynchronize());
+    if (ctx->fsq) FCD_HIP_TRY(hipFree(ctx->fsq));
+    ctx->fsq = nullptr;
+    ctx->fsq_bytes = 0;
+    FCD_HIP_TRY(hipMalloc(&ctx->fsq, bytes));
+    ctx->fsq_bytes = bytes;
+    ctx->n_alloc += 1;
+    return FCD_OK;
+}
+
+void fcd_sweep_ws_bytes(const fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t GW, size_t *ws_bytes, size_t *fsq_bytes) {
+    const size_t f = fcd_f_pass_ws_bytes(Nreg, U, GW), r = fcd_r_pass_ws_bytes(Nreg, U, GW, ctx->knobs.r_path);
+    *ws_bytes = f > r ? f : r;
+    *fsq_bytes = fcd_fsq_need_bytes(Nreg, U, GW);
+}
+
+// "0", "" and unset mean "default"; anything else is the number
+static double knob_env(const char *name) {
+    const char *e = getenv(name);
+    return (e && *e) ? atof(e) : 0.0;
 }
 
 void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s) {
@@ -119,6 +144,16 @@ int fcd_ctx_create(fcd_ctx **out) {
         ctx->prof_n[i] = ctx->prof_cap[i] = 0;
     }
     ctx->msg[0] = 0;
+    ctx->n_alloc = 0;
+    for (int i = 0; i < FCD_KA_N; ++i) ctx->lds_attr[i] = 0;
+    // the only place the environment is read: defaults of the knobs (fcd_ctx_set_knob changes them later)
+    ctx->knobs.r_path = (int)knob_env("FCD_R_PATH");
+    ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");
+    ctx->knobs.r_persist = (int)knob_env("FCD_R_PERSIST");
+    ctx->knobs.r_nopad = (int)knob_env("FCD_R_NOPAD");
+    ctx->knobs.r_tol = knob_env("FCD_R_TOL");
+    ctx->knobs.f_tol = knob_env("FCD_F_TOL");
+    ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
     int rc = fcd_ws_reserve(ctx, 1u << 20);
     if (rc == FCD_OK) {
         void *pin = nullptr;
@@ -145,6 +180,7 @@ int fcd_ctx_create(fcd_ctx **out) {
             tab[64 + i] = -log(tab[i]);      // log of the ROUNDED reciprocal's inverse: the identity stays exact
         }
         hipError_t e = hipMalloc(&ctx->log_tab, sizeof(tab));
+        ctx->n_alloc += 1;
         if (e == hipSuccess) e = hipMemcpy(ctx->log_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             fcd_ctx_destroy(ctx);
@@ -176,12 +212,35 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
     size_t need = (size_t)64 * GW * 64 * sizeof(double);        // log-joint partials
     const size_t en = (size_t)ctx->num_cu * 8 * 8 * sizeof(double);  // energy partials
     if (en > need) need = en;
-    const int64_t NBLK = (Nreg + 15) / 16;
-    const size_t panel = 10 * (size_t)GW * U * 16 * 64 * sizeof(double)    // r step: partial sums of a superblock + 2 threshold buffers,
-                         + (size_t)GW * Nreg * NBLK * 64 * 4                // packed f,
-                         + (size_t)GW * U * NBLK * 64 * 2 + 512;            // per-lane r words
-    if (panel > need) need = panel;
-    return fcd_ws_reserve(ctx, need);
+    size_t sweep = 0, fsq = 0;
+    fcd_sweep_ws_bytes(ctx, Nreg, U, GW, &sweep, &fsq);             // f / r pass scratch and the square f copy
+    if (sweep > need) need = sweep;
+    int rc = fcd_ws_reserve(ctx, need);
+    if (rc) return rc;
+    return fsq ? fcd_fsq_reserve(ctx, fsq) : FCD_OK;
+}
+
+int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return FCD_ERR_ARG;
+    fcd_knobs &k = ctx->knobs;
+    if (!strcmp(name, "r_path")) k.r_path = (int)value;
+    else if (!strcmp(name, "r_ub")) k.r_ub = (int)value;
+    else if (!strcmp(name, "r_persist")) k.r_persist = (int)value;
+    else if (!strcmp(name, "r_nopad")) k.r_nopad = (int)value;
+    else if (!strcmp(name, "r_tol")) k.r_tol = value;
+    else if (!strcmp(name, "f_tol")) k.f_tol = value;
+    else if (!strcmp(name, "f_form")) k.f_form = (int)value;
+    else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");
+    return FCD_OK;
+}
+
+int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out) {
+    if (!ctx || !name || !out) return FCD_ERR_ARG;
+    if (!strcmp(name, "n_alloc")) *out = ctx->n_alloc;
+    else if (!strcmp(name, "ws_bytes")) *out = (int64_t)ctx->ws_bytes;
+    else if (!strcmp(name, "fsq_bytes")) *out = (int64_t)ctx->fsq_bytes;
+    else return FCD_ERR_ARG;
+    return FCD_OK;
 }
 
 int64_t fcd_N_to_C(int64_t Nreg) { return fcd_tri(Nreg); }

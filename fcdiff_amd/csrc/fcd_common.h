@@ -13,11 +13,31 @@
 #define FCD_PROF_RSTEP 2
 #define FCD_PROF_PACK 3
 
+// Tuning / test knobs.  Read ONCE from the environment by fcd_ctx_create (FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST,
+// FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL: "0" / unset = default), changed afterwards only through fcd_ctx_set_knob: no
+// entry point reads the environment.
+struct fcd_knobs {
+    int r_path;        // 0: blocked r pass (default); 1: row-sequential single-launch kernel (alternative, slower)
+    int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
+    int r_persist;     // 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; kept with its own test)
+    int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch
+    double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
+    double f_tol;      // > default: the same for the f draws
+    int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
+};
+
+// kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
+enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
+       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_N = FCD_KA_R_PASS + 4 };
+
 struct fcd_ctx {
     int device;
     int num_cu;
     void *ws;          // reduction / partial-sum workspace
     size_t ws_bytes;
+    fcd_knobs knobs;
+    long long n_alloc;             // device allocations made by this context so far (fcd_ctx_stat "n_alloc")
+    size_t lds_attr[FCD_KA_N];     // largest dynamic-LDS size already set per kernel
     void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
@@ -48,6 +68,22 @@ static inline int fcd_fail(fcd_ctx *ctx, int code, const char *fmt, long long a 
 }
 
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
+// square copy of the f state (see fcd_gibbs_sweeps): grown like the workspace
+int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes);
+// bytes the sweep kernels need at this shape: f pass scratch, r pass scratch (both in ctx->ws, one after the other in
+// time: the larger counts), square f copy.  ONE formula shared by fcd_ctx_reserve and the step functions.
+void fcd_sweep_ws_bytes(const fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t GW, size_t *ws_bytes, size_t *fsq_bytes);
+size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW);     // fcd_gibbs.hip
+size_t fcd_r_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW, int r_path);   // fcd_gibbs_r.hip
+size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW);      // fcd_gibbs.hip: 0 when the fused driver keeps no square copy
+// raise a kernel's dynamic-LDS limit if this size was not set before (no HIP call otherwise)
+static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t shmem) {
+    if (shmem <= 64 * 1024 || shmem <= ctx->lds_attr[slot]) return FCD_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+    ctx->lds_attr[slot] = shmem;
+    return FCD_OK;
+}
 // f / r pass with the square copy of the f state (fcd_gibbs_sweeps: the f pass also writes f of edge (n, m) at [n][m] and
 // [m][n], the r pass then packs its f words from contiguous rows instead of gathering 64-byte pieces).  fsq == nullptr:
 // the plain entry points.  Symmetric edge ids only.

@@ -414,6 +414,143 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f step, pair form for ANY number of patients (what cfg5's U = 250 runs).  Same records, same term (one
+// ds_read_b128 + two fp64 adds per PAIR of patients), but
+//   * the tile holds EC edges with EC chosen by the host so that two workgroups share a CU (EC * NPAIR * 256 B <= 80 KiB),
+//   * the pair records are built straight from global memory (no single rows in LDS: at U = 250 they would cost
+//     12 KB per edge), four (edge, pair) records per thread in flight,
+//   * the slot words of a group of 16 patients are loaded per group, one group ahead (a wave cannot hold the
+//     16 words per region that U = 250 needs), the group loop is a run-time loop.
+// One Philox block still serves four edges; a tile of EC < 4 edges recomputes it (c0 is a multiple of EC, EC | 4).
+// ---------------------------------------------------------------------------------------------
+template <int EC>
+__global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
+                                                                const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
+                                                                const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
+                                                                int GW, uint32_t chain0, uint64_t seed, uint32_t sweep,
+                                                                float margin, uint8_t *__restrict__ fsq) {
+    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [EC][NPAIR][16][2]
+    const int NPAIR = (U + 1) >> 1, NW16 = (U + 15) >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * EC;
+    const int ne = (int)((C - c0 < EC) ? (C - c0) : EC);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
+    fcd_edge_to_pair(c0, wn, wm);
+    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * NW16 * 64;
+    const uint32_t ul = (uint32_t)lane;
+    // slot words of the first group of the first edge: requested before the build so that their latency hides behind it
+    uint32_t rn_c = ru[(uint32_t)((wn * NW16) * 64) + ul], rm_c = ru[(uint32_t)((wm * NW16) * 64) + ul];
+    {
+        // pair records straight from the tile's rows of lMf (one contiguous piece of ne * U * 48 bytes): a thread keeps
+        // its slot (blockDim is a multiple of 16) and makes four records per turn, their eight 16-byte loads in flight
+        // together.  A record index beyond the tile is clamped for the loads and dropped at the store.
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        double2 *dst = reinterpret_cast<double2 *>(ptile);
+        const int slot = threadIdx.x & 15;
+        const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
+        const bool valid = !((x0 & a0) | (x1 & a1));
+        const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
+        const int total = ne * NPAIR, stride = blockDim.x >> 4;
+        constexpr int BU = 4;
+        for (int ep0 = threadIdx.x >> 4; ep0 < total; ep0 += BU * stride) {
+            double2 va[BU], vb[BU];
+            bool two[BU];
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int ep = ep0 + j * stride;
+                const int epc = ep < total ? ep : total - 1;
+                const int e = epc / NPAIR, pr = epc - e * NPAIR;
+                const int u = 2 * pr;
+                const double2 *su = src + (e * U + u) * 3;
+                two[j] = u + 1 < U;
+                va[j] = su[l0];
+                vb[j] = su[two[j] ? 3 + l1 : l0];
+            }
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int ep = ep0 + j * stride;
+                double2 v = make_double2(0.0, 0.0);
+                if (valid) {
+                    v = va[j];
+                    if (two[j]) {
+                        v.x += vb[j].x;
+                        v.y += vb[j].y;
+                    }
+                }
+                if (ep < total) dst[ep * 16 + slot] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (w >= GW) return;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
+    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
+    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    fcd_u4 rnd = {0, 0, 0, 0};
+    const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
+    typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
+    typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
+    const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ptile;   // 256-aligned
+
+    for (int e = 0; e < ne; ++e) {
+        const int64_t c = c0 + e;
+        // next edge: (n, m+1), or (n+1, 0) at the end of row n (clamped past the last edge: unused there)
+        int nn = wn, nm = wm + 1;
+        if (nm == nn) {
+            nm = 0;
+            nn = (nn + 1 < Nreg) ? nn + 1 : nn;
+        }
+        const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 256));
+        double b1 = 0.0, b2 = 0.0;
+        for (int g = 0; g < NG; ++g) {
+            // slot words of the next group (of the next edge after the last group): always loaded, from a valid place
+            const bool last = g + 1 == NG;
+            const int pn = last ? nn : wn, pm = last ? nm : wm, pg = last ? 0 : g + 1;
+            const uint32_t rn_n = ru[(uint32_t)((pn * NW16 + pg) * 64) + ul], rm_n = ru[(uint32_t)((pm * NW16 + pg) * 64) + ul];
+            const uint32_t zs = (rn_c ^ rm_c) | ((rn_c & rm_c) << 2);
+            const uint32_t gb = tb + (uint32_t)(g * (8 * 256));
+            if (NPAIR - 8 * g >= 8) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const uint32_t sh = (p == 0) ? (zs << 4) : (zs >> (4 * p - 4));
+                    uint32_t ad;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0xF0u), "v"(gb));
+                    const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(p * 256));
+                    b1 += v.x;
+                    b2 += v.y;
+                }
+            } else {
+                for (int p = 0; p < NPAIR - 8 * g; ++p) {
+                    const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
+                    const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + gb + (uint32_t)(p * 256));
+                    b1 += v.x;
+                    b2 += v.y;
+                }
+            }
+            rn_c = rn_n;
+            rm_c = rm_n;
+        }
+        b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
+        b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+        if (e == 0 || (c & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);
+        const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
+        bool amb;
+        int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
+        if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
+        (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
+        if (fsq) {
+            uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
+            (sq + ((int64_t)wn * Nreg + wm) * 64)[(uint32_t)lane] = (uint8_t)k;
+            (sq + ((int64_t)wm * Nreg + wn) * 64)[(uint32_t)lane] = (uint8_t)k;
+        }
+        wn = nn;
+        wm = nm;
+    }
+}
+
 // conditional log-weights of every r site given the CURRENT state (nothing updated): parity hook.
 __global__ __launch_bounds__(64) void gibbs_cond_r_kernel(const double *__restrict__ lM, const double *__restrict__ hyper,
                                                           const uint8_t *__restrict__ f_state,
@@ -715,10 +852,9 @@ int launch_f(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hy
     f_step_geometry(U, g.GW, Ec, wpb, shmem);
     if (shmem > 160 * 1024)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "f step: one edge's table row (U=%lld patients) exceeds the 160 KiB LDS", U);
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_kernel<COND>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return (int)e;
+    {
+        int rc = fcd_lds_attr(ctx, COND ? FCD_KA_F_COND : FCD_KA_F_GENERIC, reinterpret_cast<const void *>(&gibbs_f_kernel<COND>), shmem);
+        if (rc) return rc;
     }
     dim3 grid((unsigned)((g.C + Ec - 1) / Ec), (unsigned)((g.GW + wpb - 1) / wpb));
     hipLaunchKernelGGL(gibbs_f_kernel<COND>, grid, dim3(64 * wpb), shmem, s, S_B, lM, hyper, f_state, r_bits, (int)Nreg,
@@ -775,11 +911,53 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
                                nullptr);
 }
 
-// *fsq_used (optional) tells the caller whether the kernel that ran writes the square copy (only the pair form does)
-static bool f_step_writes_sq(const double *lMf, int64_t Nreg, int64_t U, int64_t GW) {
-    const int NW16 = (int)((U + 15) / 16);
+// Which kernel the f step runs at a shape, and with what geometry: shared by the launch code, by the workspace
+// formula (fcd_f_pass_ws_bytes) and by the fused driver (only the pair forms write the square copy).
+enum { F_GENERIC = 0, F_PAIR = 1, F_PAIRX = 2, F_DIFF = 3 };
+struct f_plan {
+    int form, NW16, EC;
+    size_t shmem;
+};
+static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int f_form) {
+    f_plan p = {F_GENERIC, (int)((U + 15) / 16), 0, 0};
+    if (!have_lMf || (size_t)U * 48 > 160 * 1024) return p;
+    const bool words_ok = GW * Nreg * p.NW16 < INT32_MAX / 4;       // r_U item index in 32 bits
     const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
-    return lMf && (size_t)U * 48 <= 160 * 1024 && NW16 <= 4 && pair_shmem <= 96 * 1024 && GW * Nreg * NW16 < INT32_MAX / 4;
+    if (f_form != F_PAIRX && f_form != F_DIFF && p.NW16 <= 4 && pair_shmem <= 96 * 1024 && words_ok) {
+        p.form = F_PAIR;
+        p.EC = FP_EC;
+        p.shmem = pair_shmem;
+        return p;
+    }
+    const size_t per_edge = (size_t)((U + 1) / 2) * 256;
+    if (f_form != F_DIFF && words_ok && per_edge <= 160 * 1024) {
+        // largest tile that still lets two workgroups share a CU; one edge per tile may take the whole LDS
+        int ec = 8;
+        while (ec > 1 && (size_t)ec * per_edge > 80 * 1024) ec >>= 1;
+        p.form = F_PAIRX;
+        p.EC = ec;
+        p.shmem = (size_t)ec * per_edge;
+        return p;
+    }
+    p.form = F_DIFF;
+    int64_t e = (int64_t)(24 * 1024 / ((size_t)U * 48));
+    if (e < 1) e = 1;
+    if (e > 8) e = 8;
+    if (e > 1) e &= ~1ll;   // even: both halves of a Philox block are used inside one tile
+    p.EC = (int)e;
+    p.shmem = (size_t)U * 48 * e;
+    return p;
+}
+
+size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW) {
+    // per-lane slot words r_U of the pair forms (the largest user; the other forms need nothing)
+    return (size_t)GW * Nreg * ((U + 15) / 16) * 64 * sizeof(uint32_t);
+}
+
+size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {
+    const f_plan p = f_plan_for(true, Nreg, U, GW, 0);
+    const size_t need = (size_t)GW * Nreg * Nreg * 64;
+    return ((p.form == F_PAIR || p.form == F_PAIRX) && need <= ((size_t)8 << 30)) ? need : 0;
 }
 
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
@@ -789,66 +967,56 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
     if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_f_step: null pointer");
-    if (!lMf || (size_t)U * 48 > 160 * 1024)
+    const f_plan pl = f_plan_for(lMf != nullptr, Nreg, U, g.GW, ctx->knobs.f_form);
+    if (pl.form == F_GENERIC)
         return launch_f<false>(ctx, S_B, lM, hyper, f_state, r_bits, Nreg, U, G, g, chain0, seed, sweep, nullptr,
                                (hipStream_t)stream);
     fcd_abl_refresh((hipStream_t)stream);
     const int wpb = g.GW < 16 ? g.GW : 16;
     hipStream_t s = (hipStream_t)stream;
     float margin = FCD_DRAW_F_MARGIN;
-    if (const char *e = getenv("FCD_F_TOL")) {   // test hook: a huge value sends every draw through fcd_draw_f
-        const float v = (float)atof(e);
-        if (v > margin) margin = v;
-    }
-    const int NW16 = (int)((U + 15) / 16);
-    const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
-    if (NW16 <= 4 && pair_shmem <= 96 * 1024 && (int64_t)g.GW * Nreg * NW16 < INT32_MAX / 4) {
-        // pair form: per-lane slot words over patients (scratch in the ctx workspace), pair records in LDS
-        const size_t ru_bytes = (size_t)g.GW * Nreg * NW16 * 64 * sizeof(uint32_t);
-        rc = fcd_ws_reserve(ctx, ru_bytes);
+    if ((float)ctx->knobs.f_tol > margin) margin = (float)ctx->knobs.f_tol;   // test hook: huge = every draw through fcd_draw_f
+    if (pl.form == F_PAIR || pl.form == F_PAIRX) {
+        // pair forms: per-lane slot words over patients (scratch in the ctx workspace), pair records in LDS
+        rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));
         if (rc) return rc;
         uint32_t *r_U = (uint32_t *)ctx->ws;
-        const int64_t items = (int64_t)g.GW * Nreg * NW16;
-        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, NW16,
+        const int64_t items = (int64_t)g.GW * Nreg * pl.NW16;
+        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, pl.NW16,
                            g.GW, r_U);
         FCD_LAUNCH_CHECK();
-        dim3 grid((unsigned)((g.C + FP_EC - 1) / FP_EC), (unsigned)((g.GW + wpb - 1) / wpb));
-        const void *fn = NW16 == 1   ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<1>)
-                         : NW16 == 2 ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<2>)
-                         : NW16 == 3 ? reinterpret_cast<const void *>(&gibbs_f_pair_kernel<3>)
-                                     : reinterpret_cast<const void *>(&gibbs_f_pair_kernel<4>);
-        if (pair_shmem > 64 * 1024) {
-            hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_shmem);
-            if (err != hipSuccess) return (int)err;
+        dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
+#define FCD_F_ARGS S_B, lMf, hyper, f_state, r_U, (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq
+#define FCD_LAUNCH_F(KERN, SLOT)                                                                              \
+    do {                                                                                                      \
+        rc = fcd_lds_attr(ctx, SLOT, reinterpret_cast<const void *>(&KERN), pl.shmem);                        \
+        if (rc) return rc;                                                                                    \
+        fcd_prof_begin(ctx, FCD_PROF_F, s);                                                                   \
+        hipLaunchKernelGGL(KERN, grid, dim3(64 * wpb), pl.shmem, s, FCD_F_ARGS);                              \
+        fcd_prof_end(ctx, FCD_PROF_F, s);                                                                     \
+    } while (0)
+        if (pl.form == F_PAIR) {
+            if (pl.NW16 == 1) FCD_LAUNCH_F(gibbs_f_pair_kernel<1>, FCD_KA_F_PAIR + 0);
+            else if (pl.NW16 == 2) FCD_LAUNCH_F(gibbs_f_pair_kernel<2>, FCD_KA_F_PAIR + 1);
+            else if (pl.NW16 == 3) FCD_LAUNCH_F(gibbs_f_pair_kernel<3>, FCD_KA_F_PAIR + 2);
+            else FCD_LAUNCH_F(gibbs_f_pair_kernel<4>, FCD_KA_F_PAIR + 3);
+        } else {
+            if (pl.EC == 8) FCD_LAUNCH_F(gibbs_f_pairx_kernel<8>, FCD_KA_F_PAIR_BIG + 0);
+            else if (pl.EC == 4) FCD_LAUNCH_F(gibbs_f_pairx_kernel<4>, FCD_KA_F_PAIR_BIG + 1);
+            else if (pl.EC == 2) FCD_LAUNCH_F(gibbs_f_pairx_kernel<2>, FCD_KA_F_PAIR_BIG + 2);
+            else FCD_LAUNCH_F(gibbs_f_pairx_kernel<1>, FCD_KA_F_PAIR_BIG + 3);
         }
-        fcd_prof_begin(ctx, FCD_PROF_F, s);
-#define FCD_LAUNCH_F_PAIR(NW)                                                                                              \
-    hipLaunchKernelGGL(gibbs_f_pair_kernel<NW>, grid, dim3(64 * wpb), pair_shmem, s, S_B, lMf, hyper, f_state, r_U, (int)Nreg, \
-                       (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq)
-        if (NW16 == 1) FCD_LAUNCH_F_PAIR(1);
-        else if (NW16 == 2) FCD_LAUNCH_F_PAIR(2);
-        else if (NW16 == 3) FCD_LAUNCH_F_PAIR(3);
-        else FCD_LAUNCH_F_PAIR(4);
-#undef FCD_LAUNCH_F_PAIR
-        fcd_prof_end(ctx, FCD_PROF_F, s);
+#undef FCD_LAUNCH_F
+#undef FCD_F_ARGS
         FCD_LAUNCH_CHECK();
         return FCD_OK;
     }
-    // U > 64: log-odds form with scalar r masks
-    const size_t per_edge = (size_t)U * 48;
-    int64_t e = (int64_t)(24 * 1024 / per_edge);
-    if (e < 1) e = 1;
-    if (e > 8) e = 8;
-    if (e > 1) e &= ~1ll;   // even: both halves of a Philox block are used inside one tile
-    const size_t shmem = per_edge * e;
-    if (shmem > 64 * 1024) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_f_diff_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (err != hipSuccess) return (int)err;
-    }
-    dim3 grid((unsigned)((g.C + e - 1) / e), (unsigned)((g.GW + wpb - 1) / wpb));
-    hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), shmem, s, S_B, lMf, hyper, f_state, r_bits,
-                       (int)Nreg, (int)U, g.C, g.GW, (int)e, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
+    // a patient row that fits no pair tile (U > 1280): log-odds form with scalar r masks
+    rc = fcd_lds_attr(ctx, FCD_KA_F_DIFF, reinterpret_cast<const void *>(&gibbs_f_diff_kernel), pl.shmem);
+    if (rc) return rc;
+    dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
+    hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), pl.shmem, s, S_B, lMf, hyper, f_state, r_bits,
+                       (int)Nreg, (int)U, g.C, g.GW, pl.EC, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -877,24 +1045,20 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
                                 fcd_stream stream) {
     if (n_sweeps < 0 || sweep0 < 0 || sweep0 + n_sweeps > (1ll << 32))
         return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_sweeps: sweep range [%lld, +%lld) outside the 32-bit counter word", sweep0, n_sweeps);
-    // symmetric edge ids + the pair-form f kernel + the blocked r pass: the f pass leaves a square copy of the f state
-    // from which the r pass packs its f words (contiguous rows instead of 64-byte gathers: ~40 us -> ~10 us at cfg3)
+    // symmetric edge ids + a pair-form f kernel + the blocked r pass: the f pass leaves a square copy of the f state
+    // from which the r pass packs its f words (contiguous rows instead of 64-byte gathers: ~40 us -> ~10 us at cfg3).
+    // The copy lives in the context (fcd_ctx_reserve sizes it; a first call at a larger shape grows it here, which
+    // synchronises -- the one case the header names).
     uint8_t *fsq = nullptr;
-    if (ctx && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 &&
-        f_step_writes_sq(lMf, Nreg, U, (G + 63) / 64)) {
-        const size_t need = (size_t)((G + 63) / 64) * Nreg * Nreg * 64;
-        if (need > ctx->fsq_bytes && need <= ((size_t)8 << 30)) {
-            FCD_HIP_TRY(hipDeviceSynchronize());
-            if (ctx->fsq) FCD_HIP_TRY(hipFree(ctx->fsq));
-            ctx->fsq = nullptr;
-            ctx->fsq_bytes = 0;
-            if (hipMalloc(&ctx->fsq, need) == hipSuccess) ctx->fsq_bytes = need;
-            else {
-                ctx->fsq = nullptr;           // an optimisation only: carry on without the copy
-                (void)hipGetLastError();
-            }
+    if (ctx && lMf && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 && ctx->knobs.r_path == 0) {
+        const int64_t GW = (G + 63) / 64;
+        const f_plan pl = f_plan_for(true, Nreg, U, GW, ctx->knobs.f_form);
+        const size_t need = (size_t)GW * Nreg * Nreg * 64;
+        if ((pl.form == F_PAIR || pl.form == F_PAIRX) && need <= ((size_t)8 << 30)) {
+            int rc = fcd_fsq_reserve(ctx, need);
+            if (rc) return rc;
+            fsq = (uint8_t *)ctx->fsq;
         }
-        if (need <= ctx->fsq_bytes) fsq = (uint8_t *)ctx->fsq;
     }
     for (int64_t i = 0; i < n_sweeps; ++i) {
         int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,

@@ -902,10 +902,9 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
 
 template <int UB, int WPE>
 int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s) {
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return (int)e;
+    {
+        int rc = fcd_lds_attr(ctx, FCD_KA_R_STEP + (UB == 4 ? 2 : UB - 1), reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), shmem);
+        if (rc) return rc;
     }
     fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
     hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(64 * a.wpb), shmem, s, a);
@@ -917,9 +916,9 @@ int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s)
 template <int UB, int WPE>
 int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool *fits, hipStream_t s) {
     const void *fn = reinterpret_cast<const void *>(&gibbs_r_pass_kernel<UB, WPE>);
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return (int)e;
+    {
+        int rc = fcd_lds_attr(ctx, FCD_KA_R_PASS + (UB == 4 ? 2 : UB - 1), fn, shmem);
+        if (rc) return rc;
     }
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * a.wpb, shmem);
@@ -933,7 +932,34 @@ int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool
     return FCD_OK;
 }
 
+// workspace of the blocked path: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags   (one formula for reserve and launch)
+struct r_ws_layout {
+    size_t t_bytes, f_bytes, r_bytes, s_bytes, flag_words, total;
+};
+static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
+    r_ws_layout L;
+    const int64_t NBLK = (Nreg + R_NB - 1) / R_NB;
+    L.t_bytes = (size_t)GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
+    L.f_bytes = (size_t)GW * Nreg * NBLK * 64 * sizeof(uint2);
+    L.r_bytes = ((size_t)GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
+    L.s_bytes = (size_t)GW * U * NBLK * 64 * sizeof(uint2);
+    const int64_t nWGs = (GW + 15) / 16;
+    L.flag_words = (size_t)2 * nWGs * U * NBLK + 1;                 // (at most U chunks) + the error word
+    L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.r_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
+    return L;
+}
+static size_t r_ws_seq(int64_t Nreg, int64_t U, int64_t GW) {
+    const int MSsel = (Nreg <= 256) ? 8 : 16;
+    return (size_t)GW * Nreg * MSsel * 64 * sizeof(uint64_t) + (size_t)GW * U * Nreg * 64 * sizeof(double) + 512;
+}
+
 }  // namespace
+
+size_t fcd_r_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW, int r_path) {
+    const size_t per_u_need = (size_t)((Nreg + R_NB - 1) / R_NB) * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
+    if (per_u_need > 156 * 1024 || Nreg + U > 65535) return 0;          // generic kernel: no scratch
+    return r_path == 1 ? r_ws_seq(Nreg, U, GW) : r_ws_blocked(Nreg, U, GW).total;
+}
 
 extern "C" int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMd,
                                        fcd_stream stream) {
@@ -989,15 +1015,13 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         // 0 (default): blocked panel/diagonal kernels; 1: row-sequential kernel.  Measured at cfg3: 0.59 ms vs 0.81 ms --
         // the row-sequential form pays ~10 VALU instructions per term (the blocked panel ~2 per region, thanks to pair
         // records and f/r words shared by the patients of a workgroup) and leaves CUs unevenly loaded (400 workgroups).
-        int path = 0;
-        if (const char *e = getenv("FCD_R_PATH")) path = atoi(e);
+        const int path = ctx->knobs.r_path;
         const int MSsel = (Nreg <= 256) ? 8 : 16;
         const size_t seq_lds = ((size_t)2 * Nreg * 6 + (size_t)2 * 16 * 64) * sizeof(double);
         if (path == 1 && Nreg <= 32 * MSsel && Nreg * 3 <= 2048 && seq_lds <= 64 * 1024 &&
             (int64_t)g.GW * Nreg * MSsel < INT32_MAX / 4 && g.C * 64 <= INT32_MAX) {
             const size_t f2_bytes = (size_t)g.GW * Nreg * MSsel * 64 * sizeof(uint64_t);
-            const size_t thr_bytes = (size_t)g.GW * U * Nreg * 64 * sizeof(double);
-            rc = fcd_ws_reserve(ctx, f2_bytes + thr_bytes + 512);
+            rc = fcd_ws_reserve(ctx, r_ws_seq(Nreg, U, g.GW));
             if (rc) return rc;
             uint64_t *f2 = (uint64_t *)ctx->ws;
             double *thr_all = (double *)((char *)ctx->ws + f2_bytes);
@@ -1029,15 +1053,11 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     }
     // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
-    const size_t t_bytes = (size_t)g.GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
-    const size_t f_bytes = (size_t)g.GW * Nreg * NBLK * 64 * sizeof(uint2);
-    const size_t r_bytes = ((size_t)g.GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
-    const size_t s_bytes = (size_t)g.GW * U * NBLK * 64 * sizeof(uint2);
-    const int nWGs = (g.GW + 15) / 16;
-    const size_t flag_words = (size_t)2 * nWGs * U * NBLK + 1;                   // (at most U chunks) + the error word
+    const r_ws_layout L = r_ws_blocked(Nreg, U, g.GW);
+    const size_t t_bytes = L.t_bytes, f_bytes = L.f_bytes, r_bytes = L.r_bytes, s_bytes = L.s_bytes;
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX || (int64_t)g.GW * U * R_NB > INT32_MAX / 64)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
-    rc = fcd_ws_reserve(ctx, 2 * t_bytes + f_bytes + 2 * r_bytes + 2 * s_bytes + flag_words * sizeof(uint32_t) + 512);
+    rc = fcd_ws_reserve(ctx, L.total);
     if (rc) return rc;
     char *wsp = (char *)ctx->ws;
     double *Pb[2] = {(double *)wsp, (double *)(wsp + t_bytes)};
@@ -1055,8 +1075,8 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     // (2 patients: two workgroups fit a CU, whose staging / pair-build / term phases then overlap; measured best at cfg3)
     int ub = 1;
     while (ub < 2 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
-    if (const char *e = getenv("FCD_R_UB")) {   // tuning knob: patients per panel workgroup (1, 2, 4)
-        const int v = atoi(e);
+    {   // tuning knob: patients per panel workgroup (1, 2, 4)
+        const int v = ctx->knobs.r_ub;
         if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_u <= 156 * 1024) ub = v;
     }
     size_t shmem = (size_t)ub * per_u;
@@ -1075,13 +1095,9 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.ncu = ctx->num_cu; a.npad = 0;
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
-    if (const char *e = getenv("FCD_R_TOL")) {   // test hook: a huge value sends every draw through the exact path
-        const double v = atof(e);
-        if (v > a.tol) a.tol = v;
-    }
+    if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
-    int persist = 0;
-    if (const char *e = getenv("FCD_R_PERSIST")) persist = atoi(e);
+    const int persist = ctx->knobs.r_persist;     // EXPERIMENTAL one-launch form (slower)
     {
         // one launch packs the f words of every region and the r words of every patient
         dim3 pgrid((unsigned)((NBLK + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
@@ -1121,7 +1137,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         a.s = st;
         a.nD = st >= 1 ? (int)U * a.nWG : 0;
         a.nP = rows * nUC * a.nWG;
-        a.npad = (getenv("FCD_R_NOPAD") == nullptr && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+        a.npad = (!ctx->knobs.r_nopad && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
         if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s);
         else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s);
         else rc = launch_step<1, 8>(ctx, a, shmem, s);

@@ -3,7 +3,11 @@
  * fit path.  Plain C: raw device pointers, sizes, a hipStream_t passed as void*.  No torch, no
  * C++ types.  Every function returns 0 on success, a negative FCD_ERR_* for an argument error
  * detected on the host, or a positive hipError_t.  Nothing throws; nothing synchronises the
- * device unless its comment says so.  There is no global state: all of it sits behind fcd_ctx.
+ * device or allocates unless its comment says so (fcd_ctx_create / fcd_ctx_destroy / fcd_ctx_reserve do; any
+ * sampler or fit entry point does ONLY when it meets a shape larger than fcd_ctx_reserve was told: it then grows
+ * the context's scratch once, which is a hipDeviceSynchronize + hipMalloc -- fcd_ctx_stat "n_alloc" counts them).
+ * There is no global state: all of it sits behind fcd_ctx.  No entry point reads the environment; the tuning /
+ * test knobs take their defaults from it once, in fcd_ctx_create.
  *
  * The reference (andy-sweet/fcdiff) is pure Python/NumPy and has NO native interface; what each
  * entry point replaces is therefore a NumPy method of fcdiff/fit.py, cited per function.  The
@@ -62,10 +66,25 @@ const char *fcd_last_message(const fcd_ctx *ctx);
 
 /* Context on the CURRENT hip device: reduction workspace + device properties.  create/destroy
  * allocate/free device memory (they synchronise); nothing else does, except that a call needing a
- * larger workspace than any before grows it (hipMalloc) -- call fcd_ctx_reserve first to avoid that. */
+ * larger workspace than any before grows it (hipDeviceSynchronize + hipMalloc) -- call fcd_ctx_reserve
+ * first to avoid that. */
 int fcd_ctx_create(fcd_ctx **out);
 int fcd_ctx_destroy(fcd_ctx *ctx);
+/* Sizes every scratch buffer of the sweep at this shape (f / r pass workspace, square f copy): after it no
+ * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
+/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL,
+ * FCD_F_FORM, read once by fcd_ctx_create; 0 = default everywhere):
+ *   "r_path"    1: row-sequential single-launch r pass instead of the blocked one (alternative, slower)
+ *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
+ *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
+ *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch
+ *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
+ *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
+ * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
+int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value);
+/* Counters of the context: "n_alloc" device allocations made so far, "ws_bytes", "fsq_bytes". */
+int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out);
 
 /* Optional timing of the library's main kernels with HIP events recorded on the launch stream, each pair
  * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r block step (or one-launch pass), 3 r pack.

@@ -57,6 +57,20 @@ def up(env, a, dtype=None):
     return env.torch.as_tensor(np.ascontiguousarray(a), device="cuda")
 
 
+@pytest.fixture
+def knobs(env):
+    """Set tuning / test knobs of the shared context (fcd_ctx_set_knob) for one test; all back to default afterwards."""
+    touched = []
+
+    def set_(**kw):
+        for (k, v) in kw.items():
+            env.ctx.set_knob(k, v)
+            touched.append(k)
+    yield set_
+    for k in touched:
+        env.ctx.set_knob(k, 0)
+
+
 # ------------------------------------------------------------------------------------------------
 # K_lik: UnsharedRegionFit._update_lps  (test_fcdiff/test_fit.py:131-166)
 # ------------------------------------------------------------------------------------------------
@@ -392,9 +406,9 @@ def test_gibbs_conditionals_against_reference_pins(env, tag):
 
 @pytest.mark.parametrize("N,U,G,mode", [(10, 4, 64, "symmetric"), (35, 6, 130, "reference"), (200, 3, 64, "symmetric"),
                                         (257, 2, 64, "symmetric")])
-def test_gibbs_row_sequential_r_pass(env, monkeypatch, N, U, G, mode):
-    """The alternative single-launch r pass (FCD_R_PATH=1; 8 or 16 splits of the regions) gives the oracle's chains too."""
-    monkeypatch.setenv("FCD_R_PATH", "1")
+def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
+    """The alternative single-launch r pass (knob r_path=1; 8 or 16 splits of the regions) gives the oracle's chains too."""
+    knobs(r_path=1)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 99 + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=4, seed=seed, edge_index=mode, ctx=env.ctx)
@@ -412,20 +426,20 @@ def test_gibbs_row_sequential_r_pass(env, monkeypatch, N, U, G, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [{"FCD_R_PERSIST": "0"}, {"FCD_R_PERSIST": "1"}, {"FCD_R_TOL": "1e30"},
-                                   {"FCD_R_PERSIST": "1", "FCD_R_TOL": "1e30"}, {"FCD_R_UB": "1"}, {"FCD_F_TOL": "1e30"}],
+@pytest.mark.parametrize("kn", [{"r_persist": 0}, {"r_persist": 1}, {"r_tol": 1e30},
+                                {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
+                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
-                              "exact-f-draws"])
+                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
-def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
+def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
     Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
-    re-decision paths of the fast draws (FCD_R_TOL / FCD_F_TOL huge: every r / f draw is repeated with the exact
-    logit / exponentials) and a one-patient panel give the oracle's chains: several blocks of 16 regions, a partial
-    last block, odd U.
+    re-decision paths of the fast draws (r_tol / f_tol huge: every r / f draw is repeated with the exact
+    logit / exponentials), a one-patient panel and the other forms of the f pass give the oracle's chains: several
+    blocks of 16 regions, a partial last block, odd U.  Knobs go through fcd_ctx_set_knob (nothing reads the environment).
     """
-    for (k, v) in knobs.items():
-        monkeypatch.setenv(k, v)
+    knobs(**kn)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 5 + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
@@ -445,12 +459,15 @@ def test_gibbs_r_pass_forms(env, monkeypatch, knobs, N, U, G, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,U,G,mode", [(17, 1, 64, "symmetric"), (16, 2, 70, "symmetric"), (32, 3, 2048, "symmetric"),
                                         (250, 4, 64, "symmetric"), (33, 7, 1100, "reference"), (3, 2, 64, "symmetric"),
-                                        (48, 66, 64, "symmetric"), (100, 17, 1024, "symmetric")])
+                                        (48, 66, 64, "symmetric"), (100, 17, 1024, "symmetric"),
+                                        (20, 250, 128, "symmetric"), (11, 129, 70, "reference"), (9, 321, 64, "symmetric"),
+                                        (6, 700, 64, "symmetric")])
 def test_gibbs_sweeps_odd_shapes(env, N, U, G, mode):
     """
     Corners of the sweep kernels against the C oracle, two sweeps each: one patient, exactly one block of regions,
     more than 16 chain words (two word groups), 16 blocks of regions, a partial chain word with the reference edge
-    ids, three regions, more than 64 patients (the U > 64 form of the f pass), an odd number of patients at 1024 chains.
+    ids, three regions, more than 64 patients (the any-U pair kernel of the f pass: tiles of 8, 2, 4, 2 and 1 edges,
+    a last slot word of 5, 1 and 15 pairs of patients, odd U), an odd number of patients at 1024 chains.
     """
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=3, seed=5, edge_index=mode, ctx=env.ctx)
@@ -576,9 +593,10 @@ def test_fit_gibbs_recovers_planted_structure(env):
 
 def test_gibbs_cfg3_size_properties(env):
     """
-    BASELINE cfg 3 shape (Nreg=200, H=U=50), 1024 chains: size-independent properties --
-    the first chains equal the C oracle state for state, a re-run is bitwise identical, a shard equals the
-    matching slice of the full run, pooled counts equal a recount of the exported state.
+    BASELINE cfg 3 shape (Nreg=200, H=U=50), 1024 chains, 2 sweeps: EVERY chain equals the C oracle state for state
+    (2048 chain-sweeps of the oracle, OpenMP over chains); plus the size-independent properties -- a re-run is bitwise
+    identical, a shard equals the matching slice of the full run, pooled counts equal a recount of the exported
+    state -- and no entry point allocates once fcd_ctx_reserve has seen the shape.
     """
     (N, H, U, G) = (200, 50, 50, 1024)
     (m, S_B, lM) = tables_for(env, N, H, U, seed=33)
@@ -592,23 +610,25 @@ def test_gibbs_cfg3_size_properties(env):
         eng.sweeps(0, 2)
         return eng
     full = run(0, G)
+    n_alloc = env.ctx.stat("n_alloc")
     f_g, r_g = full.export_state()
     again = run(0, G).export_state()
+    assert env.ctx.stat("n_alloc") == n_alloc          # second engine at the same shape: no hipMalloc, no sync
     assert np.array_equal(f_g, again[0]) and np.array_equal(r_g, again[1])
     shard = run(640, 128).export_state()
     assert np.array_equal(f_g[640:768], shard[0]) and np.array_equal(r_g[640:768], shard[1])
     c = full.stats().cpu().numpy()
     assert c[0] == r_g.sum() and [c[1], c[2], c[3]] == [(f_g == k).sum() for k in range(3)] and c[4] == G
-    # oracle: chains 0..3 and 1020..1023
+    # oracle: all 1024 chains
     lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    for c0 in (0, 1020):
-        f_o, r_o = env.CO.gibbs_init(4, N, U, 0.05, seed, c0)
-        for s in range(2):
-            env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, c0)
-            env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, 1, c0)
-        assert np.array_equal(f_g[c0:c0 + 4], f_o) and np.array_equal(r_g[c0:c0 + 4], r_o)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.05, seed, 0)
+    for s in range(2):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, 1, 0)
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
     lj = full.logjoint().cpu().numpy()
-    nptest.assert_allclose(lj[:4], env.CO.gibbs_logjoint(f_g[:4].copy(), r_g[:4].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
+    nptest.assert_allclose(lj[:8], env.CO.gibbs_logjoint(f_g[:8].copy(), r_g[:8].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
 
 
 def test_gibbs_cfg2_full_size_against_oracle(env):
@@ -630,12 +650,14 @@ def test_gibbs_cfg2_full_size_against_oracle(env):
     nptest.assert_array_equal(r_g, r_o)
 
 
-def test_gibbs_cfg5_shape_properties(env):
+def test_gibbs_cfg5_full_size(env):
     """
-    BASELINE cfg 5 shape (Nreg=400, C=79 800, H=U=250) with 128 chains: U > 64 takes the scalar-mask f kernel, the
-    r pass walks 25 blocks of 16 regions.  First chains equal the C oracle, a shard equals its slice, counts recount.
+    BASELINE cfg 5, one GPU's share at FULL size: Nreg=400 (C=79 800), H=U=250, 1024 chains.  U > 64 runs the any-U
+    pair kernel of the f pass (tiles of 2 edges, 16 slot words per region) with the square copy, the r pass walks 25
+    blocks of 16 regions.  Chains 0..31 and 992..1023 equal the C oracle state for state; a shard equals its slice;
+    pooled counts equal a recount; the tables equal the oracle's.
     """
-    (N, H, U, G) = (400, 250, 250, 128)
+    (N, H, U, G) = (400, 250, 250, 1024)
     m = env.pkg.UnsharedRegionModel()
     (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=55)
     fit = new_fit(env)
@@ -653,18 +675,20 @@ def test_gibbs_cfg5_shape_properties(env):
         return eng
     full = run(0, G)
     f_g, r_g = full.export_state()
-    shard = run(64, 64).export_state()
-    assert np.array_equal(f_g[64:], shard[0]) and np.array_equal(r_g[64:], shard[1])
     c = full.stats().cpu().numpy()
-    assert c[0] == r_g.sum(dtype=np.int64) and [c[1], c[2], c[3]] == [(f_g == k).sum() for k in range(3)]
+    del full
+    shard = run(960, 64).export_state()
+    assert np.array_equal(f_g[960:], shard[0]) and np.array_equal(r_g[960:], shard[1])
+    assert c[0] == r_g.sum(dtype=np.int64) and [c[1], c[2], c[3]] == [(f_g == k).sum() for k in range(3)] and c[4] == G
     S_B, lM = S_B_d.cpu().numpy(), lM_d.cpu().numpy()
     S_Bo, lMo = env.CO.lik_tables(b, bt, m.theta())
     nptest.assert_allclose(lM, lMo, **TAB)
     lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    f_o, r_o = env.CO.gibbs_init(2, N, U, 0.05, seed, 0)
-    env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, 0, 0)
-    env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, 0, 1, 0)
-    assert np.array_equal(f_g[:2], f_o) and np.array_equal(r_g[:2], r_o)
+    for c0 in (0, 992):
+        f_o, r_o = env.CO.gibbs_init(32, N, U, 0.05, seed, c0)
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, 0, c0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, 0, 1, c0)
+        assert np.array_equal(f_g[c0:c0 + 32], f_o) and np.array_equal(r_g[c0:c0 + 32], r_o)
 
 
 @pytest.mark.parametrize("S,N,T", [(3, 10, 200), (2, 37, 53), (5, 64, 400), (1, 2, 2), (2, 17, 1201)])
