@@ -102,8 +102,32 @@ class UnsharedRegionFit(object):
         lM = self._d.get("lM")
         if lM is None:
             raise ValueError("tables have not been initialized (_init_lps / _update_lps)")
+        if lM.dim() != 4 or tuple(lM.shape[2:]) != (3, 3):
+            raise ValueError("_lM must have shape (C, U, 3, 3), got %s" % (tuple(lM.shape),))
         C, U = int(lM.shape[0]), int(lM.shape[1])
-        return int(round(float(util.C_to_N(C)))), C, U
+        N = util.C_to_N(C)
+        if (N % 1) != 0:
+            raise ValueError("Number of connections (%u) must be a triangular number." % C)
+        return int(N), C, U
+
+    def _check_state(self, need=("lq_R", "lq_F", "S_B")):
+        """
+        (N, C, U) from the tables, after checking that every buffer a kernel is about to index has the shape the
+        kernel assumes.  The private state is assignable as NumPy arrays (the reference's tests do it); a mismatch
+        there is a NumPy broadcasting error in the reference -- here it would be an out-of-bounds device read, so it
+        is refused on the host before anything is launched.
+        """
+        (N, C, U) = self._shape()
+        want = {"lq_R": (N, U, 2), "lq_F": (C, 1, 3), "S_B": (C, 3)}
+        for key in need:
+            v = self._d.get(key)
+            if v is None:
+                raise ValueError("_%s has not been initialized (_init_lps)" % key)
+            if tuple(v.shape) != want[key]:
+                raise ValueError("_%s has shape %s, the tables (_lM %s) need %s"
+                                 % (key if key != "S_B" else "lp_B_g_F (summed over H)", tuple(v.shape),
+                                    (C, U, 3, 3), want[key]))
+        return (N, C, U)
 
     def _hyper(self):
         """Device hyper block {ln gamma, ln(1-pi), ln pi} refreshed whenever the model's values changed."""
@@ -240,9 +264,13 @@ class UnsharedRegionFit(object):
         bt = np.ascontiguousarray(self.bt, dtype=np.float64)
         (C, H) = b.shape
         U = bt.shape[1]
-        if self._d.get("b_src") is not self.b or self._d.get("bt_src") is not self.bt:
-            self._d["b"], self._d["bt"] = self._up(b), self._up(bt)      # uploaded once per dataset
-            self._d["b_src"], self._d["bt_src"] = self.b, self.bt
+        # uploaded once per dataset: re-uploaded when fit.b / fit.bt are other arrays, other shapes, or their contents
+        # changed in place (a strided-sample checksum sees whole-array edits -- scaling, clipping, Fisher z; after an
+        # edit of a few single elements call invalidate_data())
+        key = (id(self.b), id(self.bt), b.shape, bt.shape, self._data_digest(b), self._data_digest(bt))
+        if self._d.get("data_key") != key:
+            self._d["b"], self._d["bt"] = self._up(b), self._up(bt)
+            self._d["data_key"] = key
         if self._d.get("S_B") is None or tuple(self._d["S_B"].shape) != (C, 3):
             self._d["S_B"] = t.empty((C, 3), dtype=t.float64, device=dev)
         if self._d.get("lM") is None or tuple(self._d["lM"].shape) != (C, U, 3, 3):
@@ -257,6 +285,17 @@ class UnsharedRegionFit(object):
                              _lib.stream_ptr())
         self._d["lpB"], self._d["pBt"] = lpB, pBt
 
+    @staticmethod
+    def _data_digest(a):
+        flat = a.reshape(-1)
+        step = max(1, flat.shape[0] // 4096)
+        sample = flat[::step]
+        return (float(sample.sum()), float(np.abs(sample).sum()), float(flat[-1]) if flat.shape[0] else 0.0)
+
+    def invalidate_data(self):
+        """Forget the device copies of b / bt: the next _update_lps() uploads them again (after in-place edits)."""
+        self._d.pop("data_key", None)
+
     def _is_converged(self, s):
         """fit.py:124-140 (quirk Q6 kept: a negative energy makes any decrease 'converged')."""
         e = self.energy[s - 1]
@@ -269,7 +308,7 @@ class UnsharedRegionFit(object):
 
     def _energy_terms(self):
         t = self._torch()
-        (N, C, U) = self._shape()
+        (N, C, U) = self._check_state()
         out = t.empty(6, dtype=t.float64, device=self._dev())
         self._context().call("fcd_vb_energy", _lib.dptr(self._d["lq_F"]), _lib.dptr(self._d["lq_R"]),
                              _lib.dptr(self._d["S_B"]), _lib.dptr(self._d["lM"]), _lib.dptr(self._hyper()), N, U,
@@ -282,7 +321,7 @@ class UnsharedRegionFit(object):
     def _update_lq_F(self):
         """Probability of the typical network template (fit.py:157-174): kernel K_qF."""
         t = self._torch()
-        (N, C, U) = self._shape()
+        (N, C, U) = self._check_state(need=("lq_R", "S_B"))
         out = t.empty((C, 1, 3), dtype=t.float64, device=self._dev())
         self._context().call("fcd_vb_update_qF", _lib.dptr(self._d["lq_R"]), _lib.dptr(self._d["S_B"]),
                              _lib.dptr(self._d["lM"]), _lib.dptr(self._hyper()), N, U, _lib.dptr(out),
@@ -291,7 +330,7 @@ class UnsharedRegionFit(object):
 
     def _update_lq_R(self):
         """Probability of the anomalous regions (fit.py:176-198): kernel K_qR (Gauss-Seidel over regions)."""
-        (N, C, U) = self._shape()
+        (N, C, U) = self._check_state(need=("lq_R", "lq_F"))
         lq_R = self._d["lq_R"].clone()
         self._context().call("fcd_vb_update_qR", _lib.dptr(self._d["lq_F"]), _lib.dptr(self._d["lM"]),
                              _lib.dptr(self._hyper()), N, U, _lib.EDGE_MODES[self._edge_mode()], _lib.dptr(lq_R),
@@ -305,9 +344,16 @@ class UnsharedRegionFit(object):
         if self.update_theta_sub:
             self._update_theta_sub()
 
-    def _theta_step(self):
+    def _theta_step(self, lq_R=None, lq_F=None):
+        """out4 = {mean q_R[:,:,1], mean_c q_F} from the given (or the current) log-probabilities."""
         t = self._torch()
-        lq_R, lq_F = self._d["lq_R"], self._d["lq_F"]
+        lq_R = self._d.get("lq_R") if lq_R is None else lq_R
+        lq_F = self._d.get("lq_F") if lq_F is None else lq_F
+        if lq_R is None or lq_F is None:
+            raise ValueError("_lq_R / _lq_F have not been initialized (_init_lps)")
+        if lq_R.dim() != 3 or int(lq_R.shape[2]) != 2 or lq_F.dim() != 3 or tuple(lq_F.shape[1:]) != (1, 3):
+            raise ValueError("_lq_R must have shape (N, U, 2) and _lq_F (C, 1, 3), got %s and %s"
+                             % (tuple(lq_R.shape), tuple(lq_F.shape)))
         (N, U) = (int(lq_R.shape[0]), int(lq_R.shape[1]))
         if util.N_to_C(N) != int(lq_F.shape[0]):
             raise ValueError("_lq_F and _lq_R disagree on the number of regions")
@@ -319,20 +365,30 @@ class UnsharedRegionFit(object):
     def _update_pi(self):
         """pi* = mean q_R[:, :, 1] (fit.py:208-213); a scalar, as in the reference."""
         t = self._torch()
-        lq_R = self._d["lq_R"]
-        if self._d.get("lq_F") is None:      # the reference's test sets only _lq_R
-            N = int(lq_R.shape[0])
-            self._d["lq_F"] = t.full((util.N_to_C(N), 1, 3), -np.log(3), dtype=t.float64, device=self._dev())
-        self.model.pi = float(self._theta_step()[0])
+        lq_R = self._d.get("lq_R")
+        if lq_R is None:
+            raise ValueError("_lq_R has not been initialized (_init_lps)")
+        # pi* needs q_R only (the reference's test sets nothing else, test_fit.py:513-533): q_F is a local stand-in
+        # of the matching size, never stored
+        lq_F = self._d.get("lq_F")
+        if lq_F is None or lq_R.dim() != 3 or int(lq_F.shape[0]) != util.N_to_C(int(lq_R.shape[0])):
+            lq_F = t.full((util.N_to_C(int(lq_R.shape[0])), 1, 3), -np.log(3), dtype=t.float64, device=self._dev())
+        self.model.pi = float(self._theta_step(lq_R=lq_R, lq_F=lq_F)[0])
 
     def _update_gamma(self):
         """gamma* = mean_c q_F (fit.py:215-220)."""
         t = self._torch()
-        lq_F = self._d["lq_F"]
-        if self._d.get("lq_R") is None:      # the reference's test sets only _lq_F
-            N = int(round(float(util.C_to_N(int(lq_F.shape[0])))))
-            self._d["lq_R"] = t.full((N, 1, 2), -np.log(2), dtype=t.float64, device=self._dev())
-        self.model.gamma = self._theta_step()[1:4].copy()
+        lq_F = self._d.get("lq_F")
+        if lq_F is None:
+            raise ValueError("_lq_F has not been initialized (_init_lps)")
+        # gamma* needs q_F only (test_fit.py:536-557): q_R is a local (N, 1, 2) stand-in, never stored
+        N = util.C_to_N(int(lq_F.shape[0]))
+        if (N % 1) != 0:
+            raise ValueError("Number of connections (%u) must be a triangular number." % int(lq_F.shape[0]))
+        lq_R = self._d.get("lq_R")
+        if lq_R is None or int(lq_R.shape[0]) != int(N):
+            lq_R = t.full((int(N), 1, 2), -np.log(2), dtype=t.float64, device=self._dev())
+        self.model.gamma = self._theta_step(lq_R=lq_R, lq_F=lq_F)[1:4].copy()
 
     def diagnostics(self):
         """split-R-hat / effective sample size of the per-chain log-joint trace of the last gibbs run (trace_every > 0)."""
@@ -357,8 +413,8 @@ class UnsharedRegionFit(object):
     def _theta_sub_weights(self):
         """W[c,u,k,l] = q_F[c,k] * w_l(c,u) on the device (fit.py:382-406, 508-510)."""
         t = self._torch()
+        (N, _C, U) = self._check_state(need=("lq_R", "lq_F"))
         lq_R, lq_F = self._d["lq_R"], self._d["lq_F"]
-        (N, U) = (int(lq_R.shape[0]), int(lq_R.shape[1]))
         W = t.empty((util.N_to_C(N), U, 3, 3), dtype=t.float64, device=self._dev())
         self._context().call("fcd_theta_sub_weights_vb", _lib.dptr(lq_F), _lib.dptr(lq_R), N, U, _lib.dptr(W),
                              _lib.stream_ptr())

@@ -52,3 +52,54 @@ def test_derivative_helpers():
     nptest.assert_equal(F._eval_dlN_ds(g["bb"], mu, sigma), g["dlN_ds_fn"])
     nptest.assert_equal(F._eval_dN_dm(g["NN"], g["bb"], mu, sigma), g["dN_dm_fn"])
     nptest.assert_equal(F._eval_dN_ds(g["NN"], g["bb"], mu, sigma), g["dN_ds_fn"])
+
+
+def test_check_state_refuses_mismatched_private_state_before_any_launch():
+    """
+    The private state is NumPy-assignable (the reference's tests set _lq_R, _lq_F, _lM directly).  A shape that does
+    not match the tables must raise on the host -- the kernels index the buffers unconditionally.  No GPU is needed:
+    the check only looks at tensor shapes.
+    """
+    import pytest
+    import torch
+    from fcdiff_amd.fit import UnsharedRegionFit
+    (N, U) = (6, 4)
+    C = N * (N - 1) // 2
+    fit = UnsharedRegionFit()
+    fit._d["lM"] = torch.zeros((C, U, 3, 3), dtype=torch.float64)
+    fit._d["S_B"] = torch.zeros((C, 3), dtype=torch.float64)
+    fit._d["lq_R"] = torch.zeros((N, U, 2), dtype=torch.float64)
+    fit._d["lq_F"] = torch.zeros((C, 1, 3), dtype=torch.float64)
+    assert fit._check_state() == (N, C, U)
+    for (key, bad) in (("lq_R", (N, 1, 2)), ("lq_R", (N + 1, U, 2)), ("lq_F", (C - 1, 1, 3)), ("lq_F", (C, 3)),
+                       ("S_B", (C, 4)), ("lq_R", (N, U + 3, 2))):
+        good = fit._d[key]
+        fit._d[key] = torch.zeros(bad, dtype=torch.float64)
+        with pytest.raises(ValueError):
+            fit._check_state()
+        for method in (fit._update_lq_F, fit._update_lq_R, fit._eval_energy, fit._theta_sub_weights):
+            if key == "lq_F" and method == fit._update_lq_F:
+                continue            # _update_lq_F overwrites _lq_F; it does not read it
+            if key == "S_B" and method in (fit._update_lq_R, fit._theta_sub_weights):
+                continue            # these do not read S_B
+            with pytest.raises(ValueError):
+                method()            # raises before the context (and so before any GPU) is touched
+        fit._d[key] = good
+    fit._d["lM"] = torch.zeros((C - 1, U, 3, 3), dtype=torch.float64)          # not a triangular number of edges
+    with pytest.raises(ValueError, match="triangular"):
+        fit._check_state()
+    fit._d["lM"] = torch.zeros((C, U, 3), dtype=torch.float64)
+    with pytest.raises(ValueError):
+        fit._check_state()
+
+
+def test_data_digest_sees_in_place_edits():
+    from fcdiff_amd.fit import UnsharedRegionFit
+    rng = np.random.RandomState(0)
+    b = rng.rand(300, 7)
+    d0 = UnsharedRegionFit._data_digest(b)
+    b *= 0.5
+    assert UnsharedRegionFit._data_digest(b) != d0
+    d1 = UnsharedRegionFit._data_digest(b)
+    np.clip(b, 0.1, 0.4, out=b)
+    assert UnsharedRegionFit._data_digest(b) != d1
