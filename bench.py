@@ -6,20 +6,24 @@ bench.py -- posterior samples/sec of the many-chain Gibbs fit path (BASELINE.jso
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], "cfg3"): Nreg=200 regions (C=19 900 edges), 100 subjects split
+Workload (default = BASELINE.json configs[2], "cfg3"): Nreg=200 regions (C=19 900 edges), 100 subjects split
 H=U=50 (SURVEY.md section 8 assumption), 1024 chains PER GPU (weak scaling: chains shard, tables replicate).
+`--nreg 400 --subjects 500` is the per-GPU share of configs[4] ("cfg5": 1024 of its 8192 chains).
 Synthetic data from the model's own sampler at the model defaults (fcdiff/model.py:33-38), float64.
 
 One step = one full sweep of every chain on this GPU -- all C f_c draws, all Nreg*U r_nu draws -- plus the
 pooled statistics, their all-reduce over ranks (RCCL), the (pi, gamma) M-step and the marginal
-counters.  One posterior sample = one sweep of one chain; value = chains * steps / time over all ranks.
+counters: the loop is fcdiff_amd.gibbs.run_chains, the one UnsharedRegionFit(method='gibbs') runs.
+One posterior sample = one sweep of one chain; value = chains * steps / time over all ranks.
 The likelihood tables depend only on (mu, sigma, eta, epsilon), which this loop holds fixed, so they are
 built once before the timed region (and timed separately: "lik_tables").
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the r pass or the f pass,
-whichever took longer), timed with HIP events on the launch stream inside the timed region; algorithmic
-bytes per launch follow SURVEY.md section 8d (u8 state).  `cpu_baseline` is the C restatement of the same
-sampler (oracle/fcdiff_oracle.c, OpenMP over chains) on the host cores, on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the r block step or the f pass,
+whichever took longer in total), timed with HIP events on the launch stream; algorithmic bytes per launch follow
+SURVEY.md section 8d (u8 state).  `cpu_baseline` is SURVEY section 8d's mode (iii): the C restatement of the same
+sampler (oracle/fcdiff_oracle.c, OpenMP over chains) on the host cores, on a bounded sample.  `vb_iteration` puts the
+reference's OWN algorithm (one variational iteration, fcdiff/fit.py:75-82) beside it: GPU milliseconds against the
+restatement in the reference's structure (mode (i), Python loop over edges) and the whole-array NumPy form (mode (ii)).
 """
 import argparse
 import json
@@ -32,8 +36,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 LDS_CLOCK_GHZ = 2.4          # MI355X peak engine clock
-LDS_BYTES_PER_CLK_CU = 256   # profiles/r01_ubench_lds_fp64.txt: 250 B/clk/CU with ds_read_b128 (8-byte reads top out at ~180)
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
+LDS_BYTES_PER_CLK_CU = 256   # MI355X_MICROARCH.md, LDS: 64 dwords per clock and CU
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
 
 
 def main():
@@ -45,7 +49,11 @@ def main():
     ap.add_argument("--subjects", type=int, default=100)
     ap.add_argument("--chains-per-gpu", type=int, default=1024)
     ap.add_argument("--mstep-every", type=int, default=1)
+    ap.add_argument("--mstep-lag", default="auto", choices=["auto", "0", "1"],
+                    help="1: the M-step of sweep s is applied after sweep s+1, its all-reduce overlaps that sweep "
+                         "(auto: 1 with several ranks, 0 with one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vb", action="store_true", help="skip the variational-iteration comparison")
     ap.add_argument("--cpu-chains", type=int, default=0)
     args = ap.parse_args()
 
@@ -64,10 +72,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    lag = (1 if world > 1 else 0) if args.mstep_lag == "auto" else int(args.mstep_lag)
 
     import fcdiff_amd
-    from fcdiff_amd import _lib
-    from fcdiff_amd.gibbs import GibbsEngine, allreduce_counts
+    from fcdiff_amd.gibbs import GibbsEngine, run_chains
 
     (Nreg, H, U) = (args.nreg, args.subjects // 2, args.subjects - args.subjects // 2)
     G = args.chains_per_gpu
@@ -76,13 +85,15 @@ def main():
     seed = 20240601
     # which BASELINE.json config this is (configs[2] = "cfg3" is the one the metric is quoted on)
     if (Nreg, H, U, G) == (200, 50, 50, 1024):
+        cfg_key = "cfg3"
         cfg_name = "cfg3" if world == 1 else "cfg4-style (cfg3 per GPU, %d GPUs)" % world
     elif (Nreg, H, U, G) == (400, 250, 250, 1024):
+        cfg_key = "cfg5"
         cfg_name = "cfg5 per-GPU share (1024 of the 8192 chains)"
     elif (Nreg, H, U, G) == (64, 16, 16, 256):
-        cfg_name = "cfg2"
+        cfg_key = cfg_name = "cfg2"
     else:
-        cfg_name = "custom"
+        cfg_key = cfg_name = "custom"
 
     model = fcdiff_amd.UnsharedRegionModel()
     (_r, _t, _f, _ft, b, bt) = model.sample_fast(Nreg, H, U, seed=0)     # same data on every rank
@@ -108,91 +119,117 @@ def main():
     eng.set_hyper(model.gamma, model.pi2())
     eng.init(float(model.pi))
 
-    ev = {"f": [], "r": []}
-
-    def step(s, timed):
-        # timed region: the fused driver (f pass + r pass, fcd_gibbs_sweeps) exactly as fit / run_chains use it;
-        # profile pass: the same two passes as separate calls with an event between them (f / r split)
-        if timed:
-            eng.sweeps(s, 1)
-        else:
-            a, b_, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            a.record()
-            eng.f_step(s)
-            b_.record()
-            eng.r_step(s)
-            c.record()
-            ev["f"].append((a, b_))
-            ev["r"].append((b_, c))
-        do_m = bool(args.mstep_every and (s + 1) % args.mstep_every == 0)
-        counts = eng.tally(want_counts=do_m, accumulate=True)      # pooled counts + marginal counters, one pass
-        if do_m:
-            eng.mstep(allreduce_counts(counts))
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        step(s, True)
+    # ---- timed region: W warm-up steps, then exactly K steps of the sampler loop ----
+    run_chains(eng, args.warmup, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
     fence()
+    n_alloc0 = ctx.stat("n_alloc")
     t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
-        step(s, True)
+    run_chains(eng, args.steps, sweep0=args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
     fence()
     elapsed = time.perf_counter() - t0
+    allocs_in_timed_region = ctx.stat("n_alloc") - n_alloc0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # Per-kernel durations: one HIP event pair around EVERY f / step launch costs ~3.7 us per event
-    # (30 per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right
-    # after it with the pairs enabled, and only that second pass feeds the per-kernel numbers.
+
+    # ---- the collective, on its own: the 8-word all-reduce of the pooled counts ----
+    allreduce_us = None
+    if world > 1:
+        cts = eng.counts.clone()
+        for _ in range(5):
+            dist.all_reduce(cts)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(cts)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - ta) / 50 * 1e6
+
+    # ---- per-kernel durations: one HIP event pair around EVERY f / step / pack launch costs ~3.7 us per event
+    # (30+ per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right after it,
+    # pass by pass, with the pairs enabled, and only that second pass feeds the per-kernel numbers.
+    ev = {"f": [], "r": [], "t": []}
     ctx.prof_enable(True)
     for s in range(args.warmup + args.steps, args.warmup + 2 * args.steps):
-        step(s, False)
+        a, b_, c, d = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        a.record()
+        eng.f_step(s)
+        b_.record()
+        eng.r_step(s)
+        c.record()
+        eng.tally(want_counts=True, accumulate=True)
+        d.record()
+        ev["f"].append((a, b_))
+        ev["r"].append((b_, c))
+        ev["t"].append((c, d))
     torch.cuda.synchronize()
     prof = ctx.prof_collect()
     ctx.prof_enable(False)
 
-    f_pass_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["f"]]))
-    r_pass_ms = float(np.mean([a.elapsed_time(b_) for (a, b_) in ev["r"]]))
+    f_pass_ms = float(np.mean([x.elapsed_time(y) for (x, y) in ev["f"]]))
+    r_pass_ms = float(np.mean([x.elapsed_time(y) for (x, y) in ev["r"]]))
+    tally_ms = float(np.mean([x.elapsed_time(y) for (x, y) in ev["t"]]))
     kern = {k: {"total_ms": v[0], "launches": v[1], "avg_launch_ms": v[0] / max(v[1], 1)} for (k, v) in prof.items()
-            if k != "lik_kernel"}
+            if k != "lik_kernel" and v[1] > 0}
+    f_name = "gibbs_f_pair_kernel"        # event slot of the f pass (either pair form)
+    r_name = "gibbs_r_step_kernel"
     # algorithmic bytes, SURVEY.md section 8d (u8 state): lM once per pass + state
     f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
     r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
-    n_step = max(kern["gibbs_r_step_kernel"]["launches"] // max(args.steps, 1), 1)   # step launches per pass
-    per_launch_bytes = {"gibbs_f_pair_kernel": f_bytes,
+    n_step = max(kern[r_name]["launches"] // max(args.steps, 1), 1) if r_name in kern else 1   # step launches per pass
+    per_launch_bytes = {f_name: f_bytes,
                         # a step launch serves 16 of the Nreg regions' rows of the r pass
-                        "gibbs_r_step_kernel": r_bytes / n_step}
-    dom = max(("gibbs_f_pair_kernel", "gibbs_r_step_kernel"), key=lambda k: kern[k]["total_ms"])
-    dom_ms = kern[dom]["avg_launch_ms"]
-    dom_bytes = per_launch_bytes[dom]
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")    # HBM bytes per launch from the PMC passes
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+                        r_name: r_bytes / n_step}
+    have = [k for k in (f_name, r_name) if k in kern]
+    roof = None
+    dom = None
+    if have:
+        dom = max(have, key=lambda k: kern[k]["total_ms"])
+        dom_ms = kern[dom]["avg_launch_ms"]
+        dom_bytes = per_launch_bytes[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        for tname in ("r02_pmc_traffic_%s.json" % cfg_key, "r01_pmc_traffic.json" if cfg_key == "cfg3" else ""):
+            tpath = os.path.join(ROOT, "profiles", tname)                 # HBM bytes per launch from the PMC passes
+            if tname and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    break
+        roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                "launches_timed": kern[dom]["launches"],
+                "note": "dominant kernel by total time; HIP event pair around every launch (fcd_prof_*) in a second "
+                        "pass of the same K steps right after the timed region (the pairs would perturb it). The tables "
+                        "are shared by all chains of the GPU, so each table byte feeds every chain's terms: the sweep is "
+                        "bound by VALU issue and wave-wide LDS reads, not by HBM (DESIGN.md section e)"}
 
-    # What actually bounds the two sweep kernels (DESIGN.md section e): wave-wide LDS reads.  Bytes the LDS serves per
-    # launch (64 lanes x 8 or 16 bytes per read, counted from the loop structure) against the measured LDS peak.
+    # What the two sweep kernels actually lean on (DESIGN.md section e): wave-wide LDS reads and VALU issue.  Bytes the
+    # LDS serves per launch (64 lanes x 8 or 16 bytes per read, counted from the loop structure) against its peak.
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     lds_peak = n_cu * LDS_BYTES_PER_CLK_CU * LDS_CLOCK_GHZ / 1e3                                   # TB/s
     nblk = (Nreg + 15) // 16
     gw = (G + 63) // 64
     f_lds = C * gw * ((U + 1) // 2) * 64 * 16                                     # one ds_read_b128 per (edge, word, patient pair)
     r_lds_pass = gw * U * Nreg * nblk * 8 * 64 * 8                                # one ds_read_b64 per (region, patient, word, pair of regions)
-    lds = {"unit": "TB/s", "peak": lds_peak,
-           "gibbs_f_pair_kernel": f_lds / (kern["gibbs_f_pair_kernel"]["avg_launch_ms"] * 1e-3) / 1e12,
-           "gibbs_r_step_kernel": r_lds_pass / n_step / (kern["gibbs_r_step_kernel"]["avg_launch_ms"] * 1e-3) / 1e12}
-    lds["frac"] = {k: lds[k] / lds_peak for k in ("gibbs_f_pair_kernel", "gibbs_r_step_kernel")}
+    lds = {"unit": "TB/s", "peak": lds_peak}
+    if f_name in kern:
+        lds[f_name] = f_lds / (kern[f_name]["avg_launch_ms"] * 1e-3) / 1e12
+    if r_name in kern:
+        lds[r_name] = r_lds_pass / n_step / (kern[r_name]["avg_launch_ms"] * 1e-3) / 1e12
+    lds["frac"] = {k: lds[k] / lds_peak for k in (f_name, r_name) if k in lds}
 
+    sweep_bytes = 2 * 72 * C * U + 24 * C + G * (2 * C + 3 * Nreg * U)            # per sweep of G chains
     out = {
         "metric": "posterior samples/sec at R=200 ROIs, N=100 subj, 1024 chains; 1/2/4/8 GPUs",
         "value": world * G * args.steps / elapsed,
@@ -209,25 +246,25 @@ def main():
         "config": {"workload": "%s: Nreg=%d (C=%d edges), H=%d, U=%d, %d chains/GPU, collapsed Gibbs sweep + pooled "
                                "(pi,gamma) M-step every %d sweep(s), fixed tables" % (cfg_name, Nreg, C, H, U, G, args.mstep_every),
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
+                   "mstep_lag": lag, "ranks_seen": ranks_seen, "allreduce_us": allreduce_us,
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
-        "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                     "launches_timed": kern[dom]["launches"],
-                     "note": "dominant kernel by total time; HIP event pair around every launch (fcd_prof_*) in a second "
-                             "pass of the same K steps right after the timed region (the pairs would perturb it). The tables "
-                             "are shared by all chains and stay in L2 / Infinity Cache at this size, so the sweep is bound by "
-                             "wave-wide LDS reads, not by HBM (DESIGN.md section e, profiles/r01_ubench_lds_fp64.txt)"},
+        "roofline": roof,
+        "sweep_hbm": {"algorithmic_bytes_per_sweep": sweep_bytes, "achieved_GBps": sweep_bytes / (elapsed / args.steps) / 1e9,
+                      "frac_of_peak": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         "kernels": kern,
         "lds_roofline": lds,
-        "passes_ms": {"f_pass": f_pass_ms, "r_pass": r_pass_ms,
+        "passes_ms": {"f_pass": f_pass_ms, "r_pass": r_pass_ms, "tally": tally_ms,
                       "f_pass_GBps": f_bytes / (f_pass_ms * 1e-3) / 1e9, "r_pass_GBps": r_bytes / (r_pass_ms * 1e-3) / 1e9,
                       "f64_adds_per_s": (2 * C * U * G + 2 * C * U * G) / ((f_pass_ms + r_pass_ms) * 1e-3)},
         "lik_tables": {"kernel": "lik_kernel", "bound": "hbm", "algorithmic_bytes": lik_bytes, "avg_launch_ms": lik_ms,
                        "achieved": lik_bytes / (lik_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": lik_bytes / (lik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "note": "one launch; event pair on its stream, mean of %d launches" % lik_n},
+        "allocs_in_timed_region": allocs_in_timed_region,
     }
+
+    if rank == 0 and world == 1 and not args.no_vb:
+        out["vb_iteration"] = vb_iteration(np, torch, fcdiff_amd, model, b, bt, Nreg, H, U, cfg_name)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle as CO
@@ -249,12 +286,77 @@ def main():
             if t_c > 10.0 or n_sw >= 50:
                 break
         out["cpu_baseline"] = {"value": n_c * n_sw / t_c, "unit": "samples/s", "cores": cores, "kind": "port",
-                               "sample": "%d chains x %d sweeps of the same cfg3 tables with the C restatement "
-                                         "(oracle/fcdiff_oracle.c, OpenMP over chains), %.1f s" % (n_c, n_sw, t_c)}
+                               "mode": "(iii) of SURVEY.md section 8d: C restatement of the same sampler, OpenMP over chains "
+                                       "(the reference has no sampler, so modes (i)/(ii) exist for the variational "
+                                       "iteration only: see vb_iteration)",
+                               "sample": "%d chains x %d sweeps of the same %s tables with the C restatement "
+                                         "(oracle/fcdiff_oracle.c, OpenMP over chains), %.1f s" % (n_c, n_sw, cfg_key, t_c)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def vb_iteration(np, torch, fcdiff_amd, model0, b, bt, Nreg, H, U, cfg_name):
+    """
+    The reference's own algorithm at this size, unscaled, in this run: one variational iteration (q_F, q_R, pi/gamma,
+    tables, energy; fcdiff/fit.py:75-82) on the GPU against the CPU restatement in the reference's structure
+    (Python loop over edges, mode (i)), the whole-array NumPy form (mode (ii)) and the C/OpenMP form (mode (iii)).
+    The host legs start from the same state and must land on the GPU's energy.
+    """
+    import copy
+    from oracle import fcdiff_oracle as O
+    from oracle import c_oracle as CO
+    C = b.shape[0]
+    fit = fcdiff_amd.fit.UnsharedRegionFit()
+    fit.model, fit.b, fit.bt = copy.deepcopy(model0), b, bt
+    fit._init_lps(Nreg, H, U)
+    fit._update_lps()
+
+    def one():
+        fit._update_lq_F()
+        fit._update_lq_R()
+        fit._update_theta()
+        fit._update_lps()
+        return fit._eval_energy()
+    e_gpu = one()                                   # first iteration from the uniform start: the one the host legs repeat
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    n_it = 10
+    t0 = time.perf_counter()
+    for _ in range(n_it):
+        one()
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / n_it * 1e3
+    res = {"workload": "one variational iteration at %s (reference edge ids)" % cfg_name, "gpu_ms": gpu_ms,
+           "cpu_faithful_s": None, "cpu_vectorised_s": None, "cpu_c_openmp_s": None, "energy_gpu": e_gpu}
+    th = dict(pi=float(model0.pi), eta=model0.eta, epsilon=model0.epsilon, gamma=np.array(model0.gamma, dtype=np.float64),
+              mu=model0.mu, sigma=model0.sigma)
+    lq_R0 = np.full((Nreg, U, 2), -np.log(2))
+    lq_F0 = np.full((C, 1, 3), -np.log(3))
+    if C * U <= 1500000:                            # cfg3: ~4 s + ~1 s; cfg5 would take minutes in the edge loop
+        t0 = time.perf_counter()
+        (_a, _b, _t, e_f) = O.vb_iteration(lq_F0, lq_R0, b, bt, th, vectorised=False)
+        res["cpu_faithful_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        (_a, _b, _t, e_v) = O.vb_iteration(lq_F0, lq_R0, b, bt, th, vectorised=True)
+        res["cpu_vectorised_s"] = time.perf_counter() - t0
+        res["energy_cpu_faithful"], res["energy_cpu_vectorised"] = float(e_f), float(e_v)
+        res["energies_agree"] = bool(abs(e_f - e_gpu) <= 1e-9 * abs(e_f) and abs(e_v - e_gpu) <= 1e-9 * abs(e_v))
+    # mode (iii): the C restatement's kernels of the iteration (tables, q_F, q_R, tables, energy), all host cores
+    t0 = time.perf_counter()
+    S_B, lM = CO.lik_tables(b, bt, model0.theta())
+    lq_F = CO.update_lq_F(lq_R0, S_B, lM, th["gamma"])
+    lq_R = CO.update_lq_R(lq_R0, lq_F, lM, [1 - th["pi"], th["pi"]], 0)
+    CO.lik_tables(b, bt, model0.theta())
+    CO.energy_terms(lq_F, lq_R, S_B, lM, th["gamma"], [1 - th["pi"], th["pi"]])
+    res["cpu_c_openmp_s"] = time.perf_counter() - t0
+    res["cores"] = CO.max_threads()
+    res["note"] = ("cpu_faithful = oracle/fcdiff_oracle.py with the reference's Python loop over edges (one core, like the "
+                   "reference); cpu_vectorised = the same arithmetic as whole-array NumPy (one core); cpu_c_openmp = "
+                   "oracle/fcdiff_oracle.c on all host cores")
+    return res
 
 
 if __name__ == "__main__":

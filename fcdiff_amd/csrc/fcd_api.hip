@@ -138,6 +138,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->dev_err = nullptr;
     ctx->fsq = nullptr;
     ctx->fsq_bytes = 0;
+    ctx->acc = nullptr;
     ctx->prof_on = 0;
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         ctx->prof_ev[i] = nullptr;
@@ -182,6 +183,9 @@ int fcd_ctx_create(fcd_ctx **out) {
         hipError_t e = hipMalloc(&ctx->log_tab, sizeof(tab));
         ctx->n_alloc += 1;
         if (e == hipSuccess) e = hipMemcpy(ctx->log_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&ctx->acc, 8 * sizeof(unsigned long long));
+        ctx->n_alloc += 1;
+        if (e == hipSuccess) e = hipMemset(ctx->acc, 0, 8 * sizeof(unsigned long long));
         if (e != hipSuccess) {
             fcd_ctx_destroy(ctx);
             return (int)e;
@@ -198,6 +202,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     if (ctx->fsq) (void)hipFree(ctx->fsq);
+    if (ctx->acc) (void)hipFree(ctx->acc);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
         delete[] ctx->prof_ev[i];

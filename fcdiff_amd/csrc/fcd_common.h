@@ -40,6 +40,7 @@ struct fcd_ctx {
     size_t lds_attr[FCD_KA_N];     // largest dynamic-LDS size already set per kernel
     void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
+    void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
     size_t fsq_bytes;
     // optional per-kernel timing with HIP events on the launch stream (fcd_prof_enable / fcd_prof_collect)
@@ -89,7 +90,7 @@ static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t sh
 // the plain entry points.  Symmetric edge ids only.
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq);
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready);
 int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper, const uint8_t *f_state,
                         uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep,
                         int edge_mode, hipStream_t stream, const uint8_t *fsq);

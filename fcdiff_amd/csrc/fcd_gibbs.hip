@@ -617,21 +617,29 @@ __global__ __launch_bounds__(256) void gibbs_stats_kernel(const uint8_t *__restr
     if (blockIdx.x == 0 && threadIdx.x == 4) counts[4] = (unsigned long long)G;
 }
 
-__global__ void gibbs_mstep_kernel(const long long *__restrict__ counts, double sites_per_chain_r, double C,
-                                   double *__restrict__ hyper) {
-    const double Gtot = (double)counts[4];
+// (pi, gamma) from pooled counts {sum r, #f=0, #f=1, #f=2, chains}: the sample version of fit.py:208-220
+__device__ __forceinline__ void mstep_from_counts(const unsigned long long *c5, double sites_per_chain_r, double C,
+                                                  double *__restrict__ hyper) {
+    const double Gtot = (double)c5[4];
     const double n_r = Gtot * sites_per_chain_r;
-    double pi = (double)counts[0] / n_r;                  // fit.py:213 over chains
+    double pi = (double)c5[0] / n_r;                      // fit.py:213 over chains
     const double lo = 0.5 / n_r;
     pi = fmin(fmax(pi, lo), 1.0 - lo);
     hyper[FCD_H_LNPI0] = log(1.0 - pi);
     hyper[FCD_H_LNPI1] = log(pi);
     const double n_f = Gtot * C;
     for (int k = 0; k < 3; ++k) {
-        double g = (double)counts[1 + k] / n_f;           // fit.py:220 over chains
+        double g = (double)c5[1 + k] / n_f;               // fit.py:220 over chains
         g = fmax(g, 0.5 / n_f);
         hyper[FCD_H_LNGAMMA + k] = log(g);
     }
+}
+
+__global__ void gibbs_mstep_kernel(const long long *__restrict__ counts, double sites_per_chain_r, double C,
+                                   double *__restrict__ hyper) {
+    unsigned long long c5[5];
+    for (int i = 0; i < 5; ++i) c5[i] = (unsigned long long)counts[i];
+    mstep_from_counts(c5, sites_per_chain_r, C, hyper);
 }
 
 __global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restrict__ f_state,
@@ -662,13 +670,37 @@ __global__ __launch_bounds__(256) void gibbs_accum_kernel(const uint8_t *__restr
 
 // ---------------------------------------------------------------------------------------------
 // tally: pooled counts AND marginal counters in one pass over the state (f_state is read once, 16 bytes
-// per lane: a wave covers the 16 chain words x 64 chains of an edge with a single load instruction).
+// per lane: a wave covers the 16 chain words x 64 chains of an edge with a single load instruction) -- and the
+// odds and ends that used to be launches of their own around it:
+//   * the pooled counts are summed in accumulators that belong to the context (acc[0..3] + a ticket in acc[4], zero
+//     between launches): the block that draws the last ticket reads the totals, writes counts_out[0..4], runs the
+//     (pi, gamma) M-step when hyper != nullptr (one rank: the statistics need no exchange) and puts the accumulators
+//     back to zero -- no memset launch, no one-thread M-step launch;
+//   * r_U != nullptr: the per-lane slot words of the NEXT f pass (pack_ru_kernel's job) are made here from the r
+//     bits this kernel reads anyway.
+// Integer sums: any order gives the same totals.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gibbs_tally_kernel(const uint8_t *__restrict__ f_state,
-                                                           const uint64_t *__restrict__ r_bits, int64_t C, int64_t NU, int GW,
-                                                           int64_t G, unsigned long long *__restrict__ counts,
-                                                           uint32_t *__restrict__ cnt_f, uint32_t *__restrict__ cnt_r) {
+struct tally_args {
+    const uint8_t *f_state;
+    const uint64_t *r_bits;
+    int64_t C, NU, G;
+    int GW, Nreg, U, NW16;
+    unsigned long long *acc;           // context-owned: 4 sums + ticket
+    unsigned long long *counts_out;    // nullable
+    uint32_t *cnt_f, *cnt_r;           // nullable (both or neither)
+    double *hyper;                     // nullable: M-step target
+    uint32_t *r_U;                     // nullable: slot words of the next f pass
+};
+
+__global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
     __shared__ unsigned long long red[16][4];
+    __shared__ int sh_last;
+    const uint8_t *__restrict__ f_state = a.f_state;
+    const uint64_t *__restrict__ r_bits = a.r_bits;
+    uint32_t *__restrict__ cnt_f = a.cnt_f;
+    uint32_t *__restrict__ cnt_r = a.cnt_r;
+    const int64_t C = a.C, NU = a.NU, G = a.G;
+    const int GW = a.GW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 3, wrow = lane >> 2;          // 16-byte piece of the 64-byte row, chain word within a group of 16
     unsigned long long tot1 = 0, tot2 = 0, n_edges = 0;
@@ -725,22 +757,50 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const uint8_t *__rest
         if (cnt_r) atomicAdd(&cnt_r[i], sr);
         cr += sr;
     }
-    if (counts) {
-        // one set of atomics per BLOCK (same-address atomics serialise): wave sums -> LDS -> thread 0..3
-        for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
-        if (lane == 0) {
-            red[wave][0] = cr;
-            red[wave][1] = n_edges * (unsigned long long)G - tot1 - tot2;
-            red[wave][2] = tot1;
-            red[wave][3] = tot2;
+    if (a.r_U) {
+        // slot words of the next f pass: one wave per (w, n, word) item, as pack_ru_kernel
+        const int U = a.U, NW16 = a.NW16;
+        const int items = GW * a.Nreg * NW16;
+        for (int item = (int)blockIdx.x * 16 + wave; item < items; item += (int)gridDim.x * 16) {
+            const int jw = item % NW16, wn = item / NW16;               // wn = w*Nreg + n
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int u = jw * 16 + j;
+                const uint64_t word = r_bits[(int64_t)wn * U + (u < U ? u : U - 1)];
+                v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << (4 * (j >> 1) + (j & 1));
+            }
+            a.r_U[(int64_t)item * 64 + lane] = v;
         }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            unsigned long long t = 0;
-            for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
-            if (t) atomicAdd(&counts[threadIdx.x], t);
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 4) counts[4] = (unsigned long long)G;
+    }
+    if (!a.acc) return;
+    // one set of atomics per BLOCK (same-address atomics serialise): wave sums -> LDS -> threads 0..3
+    for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+    if (lane == 0) {
+        red[wave][0] = cr;
+        red[wave][1] = n_edges * (unsigned long long)G - tot1 - tot2;
+        red[wave][2] = tot1;
+        red[wave][3] = tot2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long t = 0;
+        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+        if (t) atomicAdd(&a.acc[threadIdx.x], t);
+        __threadfence();                                 // the adds are done before this block's ticket is drawn
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_last = (atomicAdd(&a.acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    __syncthreads();
+    if (sh_last && threadIdx.x == 0) {
+        __threadfence();
+        unsigned long long c5[5];
+        for (int i = 0; i < 4; ++i) c5[i] = atomicExch(&a.acc[i], 0ull);     // read at the memory side and reset
+        atomicExch(&a.acc[4], 0ull);
+        c5[4] = (unsigned long long)G;
+        if (a.counts_out)
+            for (int i = 0; i < 8; ++i) a.counts_out[i] = i < 5 ? c5[i] : 0ull;
+        if (a.hyper) mstep_from_counts(c5, (double)NU, (double)C, a.hyper);
     }
 }
 
@@ -908,7 +968,7 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
                                 uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, fcd_stream stream) {
     return fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, (hipStream_t)stream,
-                               nullptr);
+                               nullptr, false);
 }
 
 // Which kernel the f step runs at a shape, and with what geometry: shared by the launch code, by the workspace
@@ -962,7 +1022,7 @@ size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {
 
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq) {
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -981,10 +1041,12 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
         rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));
         if (rc) return rc;
         uint32_t *r_U = (uint32_t *)ctx->ws;
-        const int64_t items = (int64_t)g.GW * Nreg * pl.NW16;
-        hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, pl.NW16,
-                           g.GW, r_U);
-        FCD_LAUNCH_CHECK();
+        if (!ru_ready) {     // (inside fcd_gibbs_run the previous sweep's tally has made them already)
+            const int64_t items = (int64_t)g.GW * Nreg * pl.NW16;
+            hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, pl.NW16,
+                               g.GW, r_U);
+            FCD_LAUNCH_CHECK();
+        }
         dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
 #define FCD_F_ARGS S_B, lMf, hyper, f_state, r_U, (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq
 #define FCD_LAUNCH_F(KERN, SLOT)                                                                              \
@@ -1062,7 +1124,7 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
     }
     for (int64_t i = 0; i < n_sweeps; ++i) {
         int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,
-                                     (hipStream_t)stream, fsq);
+                                     (hipStream_t)stream, fsq, false);
         if (rc) return rc;
         rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
                                  (hipStream_t)stream, fsq);
@@ -1097,6 +1159,26 @@ extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const 
     return FCD_OK;
 }
 
+// one launch of gibbs_tally_kernel; counts / cnt_f+cnt_r / hyper / r_U each optional
+static int launch_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                        const fcd_geo &g, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, double *hyper, uint32_t *r_U,
+                        hipStream_t s) {
+    tally_args a;
+    a.f_state = f_state; a.r_bits = r_bits;
+    a.C = g.C; a.NU = Nreg * U; a.G = G;
+    a.GW = g.GW; a.Nreg = (int)Nreg; a.U = (int)U; a.NW16 = (int)((U + 15) / 16);
+    a.acc = (counts || hyper) ? (unsigned long long *)ctx->acc : nullptr;
+    a.counts_out = reinterpret_cast<unsigned long long *>(counts);
+    a.cnt_f = cnt_f; a.cnt_r = cnt_r;
+    a.hyper = hyper; a.r_U = r_U;
+    int64_t blocks = (g.C + 63) / 64;          // 16 waves x 4 edges per workgroup and round
+    const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, a);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
 extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
                                int64_t G, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream) {
     fcd_geo g;
@@ -1105,14 +1187,61 @@ extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     if (!f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: null pointer");
     if ((cnt_f == nullptr) != (cnt_r == nullptr)) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: cnt_f and cnt_r go together");
     if (!counts && !cnt_f) return FCD_OK;
+    return launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, counts, cnt_f, cnt_r, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// The sampler loop of ONE rank between two exchanges of pooled statistics (what UnsharedRegionFit(method='gibbs'),
+// run_chains and bench.py call).  Per sweep: f pass (1 launch), packing for the r pass (1), block steps of the r pass
+// (ceil(Nreg/16) + 1), tally (1) -- the tally also carries the M-step and the slot words of the next f pass.
+extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
+                             double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                             int64_t chain0, uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode,
+                             int64_t mstep_every, int64_t accumulate_from, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r,
+                             fcd_stream stream) {
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
+    if (rc) return rc;
+    if (n_sweeps < 0 || sweep0 < 0 || sweep0 + n_sweeps > (1ll << 32))
+        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_run: sweep range [%lld, +%lld) outside the 32-bit counter word", sweep0, n_sweeps);
+    if (!S_B || !lM || !hyper || !f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_run: null pointer");
+    if ((cnt_f == nullptr) != (cnt_r == nullptr)) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_run: cnt_f and cnt_r go together");
+    if (mstep_every < 0) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_run: mstep_every < 0");
     hipStream_t s = (hipStream_t)stream;
-    if (counts) FCD_HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(int64_t), s));
-    int64_t blocks = (g.C + 63) / 64;          // 16 waves x 4 edges per workgroup and round
-    const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, f_state, r_bits, g.C, Nreg * U, g.GW, G,
-                       reinterpret_cast<unsigned long long *>(counts), cnt_f, cnt_r);
-    FCD_LAUNCH_CHECK();
+    // square copy of the f state for the r pass's packing (see fcd_gibbs_sweeps)
+    uint8_t *fsq = nullptr;
+    const f_plan pl = f_plan_for(lMf != nullptr, Nreg, U, g.GW, ctx->knobs.f_form);
+    const bool pair_form = pl.form == F_PAIR || pl.form == F_PAIRX;
+    if (pair_form && lMd && edge_mode == FCD_EDGE_SYMMETRIC && ctx->knobs.r_path == 0) {
+        const size_t need = (size_t)g.GW * Nreg * Nreg * 64;
+        if (need <= ((size_t)8 << 30)) {
+            rc = fcd_fsq_reserve(ctx, need);
+            if (rc) return rc;
+            fsq = (uint8_t *)ctx->fsq;
+        }
+    }
+    if (pair_form) {
+        rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));      // the tally writes the next pass's slot words there
+        if (rc) return rc;
+    }
+    bool ru_ready = false;
+    for (int64_t i = 0; i < n_sweeps; ++i) {
+        rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready);
+        if (rc) return rc;
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
+        if (rc) return rc;
+        const bool last = i + 1 == n_sweeps;
+        const bool do_m = mstep_every > 0 && (i + 1) % mstep_every == 0;
+        const bool do_a = cnt_f && sweep0 + i >= accumulate_from;
+        // the r pass's scratch is dead once its last launch is queued: the slot words of the next f pass go to its place
+        uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)ctx->ws : nullptr;
+        int64_t *cts = (last ? counts : nullptr);
+        if (do_m || do_a || cts || r_U_next) {
+            rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
+                              do_m ? hyper : nullptr, r_U_next, s);
+            if (rc) return rc;
+        }
+        ru_ready = r_U_next != nullptr;
+    }
     return FCD_OK;
 }
 

@@ -261,8 +261,6 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
                                              const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const int x0 = st > 0 ? st - 1 : 0, x1 = st + 1;       // blocks left out of the sums
-    const int rows = (Nreg - st * R_NB < R_NB) ? (Nreg - st * R_NB) : R_NB;
-    const int nUC = (U + UB - 1) / UB;
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
     double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][16 NBLK regions * 6], zero beyond Nreg
@@ -270,7 +268,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     const int u0 = uc * UB;
     const int nu = (U - u0 < UB) ? (U - u0) : UB;
     if (FCD_ABL(1, 5)) return true;       // ablation: empty role
-    const int trec = st * 1024 + (int)blockIdx.x;
+    [[maybe_unused]] const int trec = st * 1024 + (int)blockIdx.x;
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 1);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
@@ -441,7 +439,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     double *sA = compact ? smem + D_RECS_T * 36 : smem + 2 * D_RECS_T * 36;
     double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
     if (FCD_ABL(2, 5)) return true;      // ablation: empty role
-    const int trec = (b + 1) * 1024 + (int)blockIdx.x;
+    [[maybe_unused]] const int trec = (b + 1) * 1024 + (int)blockIdx.x;
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 2);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
@@ -1072,9 +1070,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
     const size_t per_u = (size_t)NBLK * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
-    // (2 patients: two workgroups fit a CU, whose staging / pair-build / term phases then overlap; measured best at cfg3)
-    int ub = 1;
-    while (ub < 2 && (size_t)(ub * 2) * per_u <= 156 * 1024 && ub * 2 <= U) ub *= 2;
+    // Two workgroups must fit a CU so that their staging / pair-build / term phases overlap: 2 patients where their
+    // tile takes at most half the LDS (cfg3: 2 x 39.9 KB), else 1 (cfg5: 76.8 KB per patient; measured 3.99 ms per pass
+    // against 4.58 ms with 2 patients and one workgroup per CU)
+    int ub = ((size_t)4 * per_u <= 160 * 1024 && U >= 2) ? 2 : 1;
     {   // tuning knob: patients per panel workgroup (1, 2, 4)
         const int v = ctx->knobs.r_ub;
         if ((v == 1 || v == 2 || v == 4) && (size_t)v * per_u <= 156 * 1024) ub = v;

@@ -13,7 +13,7 @@ New knobs (all optional; defaults reproduce the reference):
     method       'vb' (reference algorithm) | 'gibbs' (many-chain collapsed Gibbs + MCEM for pi, gamma)
     edge_index   'reference' (fit.py:185-186 calls nm_to_c for every ordered pair: quirk Q1) |
                  'symmetric' (doc/methods.rst:646-653).  Default: 'reference' for vb, 'symmetric' for gibbs.
-    n_chains, n_sweeps, burn_in, mstep_every, seed, chain0     sampler controls
+    n_chains, n_sweeps, burn_in, mstep_every, mstep_lag, seed, chain0     sampler controls
     update_theta_sub, theta_sub_every                          (eta, epsilon) step: vb every iteration / gibbs every K sweeps
 
 Differences from the reference that are deliberate and documented:
@@ -61,6 +61,7 @@ class UnsharedRegionFit(object):
         self.n_sweeps = 100
         self.burn_in = 20
         self.mstep_every = 1
+        self.mstep_lag = 0         # gibbs: 1 = apply an M-step one period late so its all-reduce overlaps the next sweeps
         self.theta_sub_every = 0   # gibbs: re-fit (eta, epsilon) from pooled chain counts every this many sweeps (0: never)
         self.energy_every = 0
         self.trace_every = 0       # gibbs: keep every chain's log-joint every this many sweeps in `trace` (chains, draws)
@@ -455,8 +456,9 @@ class UnsharedRegionFit(object):
                 self.model.eta, self.model.epsilon = eta, epsilon
                 self._update_lps()            # tables follow theta_sub ...
                 e.refresh_tables()            # ... and so do the sampler's two difference tables
+        needs_callback = bool(self.energy_every or self.trace_every or (self.update_theta_sub and self.theta_sub_every))
         run_chains(eng, self.n_sweeps, sweep0=0, mstep_every=self.mstep_every, burn_in=self.burn_in,
-                   update_theta=True, on_sweep=record)
+                   update_theta=True, on_sweep=record if needs_callback else None, mstep_lag=self.mstep_lag)
         self.sampler = eng
         self.trace = np.stack(traces, axis=1) if traces else None
         # marginals pooled over this rank's chains and, when distributed, over all ranks

@@ -142,6 +142,23 @@ class GibbsEngine(object):
                       _lib.dptr(self.counts if with_counts else None), _lib.stream_ptr())
         return self.counts if with_counts else None
 
+    def run(self, sweep0, n_sweeps, mstep_every=0, accumulate_from=None, want_counts=False):
+        """
+        n_sweeps x (f pass, r pass, tally) in one call (fcd_gibbs_run): the tally of each sweep feeds the marginal
+        counters from sweep `accumulate_from` on (None: never), runs the (pi, gamma) M-step on this rank's pooled counts
+        every `mstep_every` sweeps (0: never -- several ranks all-reduce the returned counts and call mstep()), and
+        packs the r words of the next f pass.  Returns the counts tensor of the last sweep (or None).
+        """
+        acc = accumulate_from is not None
+        self.ctx.call("fcd_gibbs_run", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMf), _lib.dptr(self.lMd),
+                      _lib.dptr(self.hyper), _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      self.chain0, C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode, int(mstep_every),
+                      int(accumulate_from) if acc else 0, _lib.dptr(self.counts if want_counts else None),
+                      _lib.dptr(self.cnt_f if acc else None), _lib.dptr(self.cnt_r if acc else None), _lib.stream_ptr())
+        if acc:
+            self.n_accumulated += max(0, int(sweep0) + int(n_sweeps) - max(int(accumulate_from), int(sweep0)))
+        return self.counts if want_counts else None
+
     # ---- pooled statistics / M-step ----
     def stats(self):
         self.ctx.call("fcd_gibbs_stats", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
@@ -194,24 +211,64 @@ class GibbsEngine(object):
         return cf, cr
 
 
+def _world_size(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_theta=True, group=None,
-               on_sweep=None):
+               on_sweep=None, mstep_lag=0):
     """
     The sampler loop shared by UnsharedRegionFit(method='gibbs') and bench.py.
 
-    for each sweep: f step, r step; every `mstep_every` sweeps: pooled counts -> all-reduce over ranks ->
-    M-step for (pi, gamma) on the device; after `burn_in` sweeps the marginal counters accumulate.
-    `engine` is anything with sweeps/tally/mstep (the HIP engine here; the CPU tests pass an
-    oracle-backed stand-in to exercise the multi-process logic under gloo).
+    Every sweep: f pass, r pass, one tally launch (marginal counters after `burn_in` sweeps, the packed r words of the
+    next f pass).  Every `mstep_every` sweeps the pooled counts give the (pi, gamma) M-step:
+      * one rank, mstep_lag=0: inside the tally launch (fcd_gibbs_run), the whole loop is ONE call;
+      * several ranks, mstep_lag=0: counts -> blocking all-reduce (RCCL) -> fcd_gibbs_mstep, between two calls;
+      * mstep_lag=1: the M-step from the counts of period j (mstep_every sweeps) is applied after period j+1 (it
+        shapes period j+2), so the all-reduce of period j runs on the collective's stream WHILE period j+1 computes.
+        The schedule -- and with it every chain's path -- is the same for any number of ranks, one rank included.
+    `engine` is anything with run/mstep (the HIP engine here; the CPU tests pass an oracle-backed stand-in to
+    exercise the multi-process logic under gloo).
     """
-    for i in range(n_sweeps):
-        s = sweep0 + i
-        engine.sweeps(s, 1)
-        do_m = bool(update_theta and mstep_every > 0 and (i + 1) % mstep_every == 0)
-        do_a = i >= burn_in
-        if do_m or do_a:
-            counts = engine.tally(want_counts=do_m, accumulate=do_a)    # one pass over the state for both
-            if do_m:
+    import torch.distributed as dist
+    world = _world_size(group)
+    k = int(mstep_every) if (update_theta and mstep_every and mstep_every > 0) else 0
+    acc_from = sweep0 + burn_in
+    if world == 1 and on_sweep is None and not mstep_lag:
+        engine.run(sweep0, n_sweeps, mstep_every=k, accumulate_from=acc_from)
+        return
+    pending = None       # (counts clone, work handle or None): the M-step that waits for its turn (mstep_lag)
+
+    def apply(p):
+        (cl, work) = p
+        if work is not None:
+            work.wait()          # the compute stream waits for the collective; the host does not (RCCL)
+        engine.mstep(cl)
+    i = 0
+    while i < n_sweeps:
+        c = n_sweeps - i
+        if on_sweep is not None:
+            c = 1
+        if k:
+            c = min(c, k - (i % k))
+        end = i + c
+        do_m = bool(k and end % k == 0)
+        local = do_m and world == 1 and not mstep_lag
+        counts = engine.run(sweep0 + i, c, mstep_every=(c if local else 0), accumulate_from=acc_from,
+                            want_counts=do_m and not local)
+        if mstep_lag and pending is not None and do_m:      # one M-step PERIOD later, whatever the chunking
+            apply(pending)
+            pending = None
+        if do_m and not local:
+            if mstep_lag:
+                cl = counts.clone()
+                work = dist.all_reduce(cl, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
+                pending = (cl, work)
+            else:
                 engine.mstep(allreduce_counts(counts, group))
         if on_sweep is not None:
             on_sweep(i, engine)
+        i = end
+    if pending is not None:
+        apply(pending)

@@ -215,10 +215,24 @@ int fcd_gibbs_mstep(fcd_ctx *ctx, const int64_t *counts, int64_t Nreg, int64_t U
  * (uint32, device); posterior marginals = counts / (sweeps * G). */
 int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg,
                          int64_t U, int64_t G, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
-/* fcd_gibbs_stats and fcd_gibbs_accumulate in ONE pass over the state (what the sampler loop calls):
+/* fcd_gibbs_stats and fcd_gibbs_accumulate in ONE pass over the state and ONE launch (the pooled sums are kept in
+ * accumulators of the context that the kernel itself puts back to zero: no memset):
  * counts (nullable) is overwritten as by fcd_gibbs_stats; cnt_f / cnt_r (both or neither) are incremented. */
 int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U,
                     int64_t G, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
+/* The sampler loop of one rank between two exchanges of pooled statistics -- what the fit loop calls:
+ *   for i in 0 .. n_sweeps-1:   f pass, r pass (sweep number sweep0 + i), then ONE tally launch that
+ *     - adds the state to the marginal counters cnt_f / cnt_r (nullable, both or neither) when sweep0 + i >= accumulate_from,
+ *     - when mstep_every > 0 and (i + 1) % mstep_every == 0 runs the (pi, gamma) M-step of fcd_gibbs_mstep on THIS
+ *       rank's pooled counts and writes hyper (single-rank use; with several ranks pass 0, all-reduce `counts` and
+ *       call fcd_gibbs_mstep),
+ *     - makes the packed r words of the next f pass.
+ *   counts (nullable) receives the pooled statistics of the LAST sweep.
+ * ceil(Nreg/16) + 4 launches per sweep at the shapes the pair-form f kernel and the blocked r pass cover. */
+int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd, double *hyper,
+                  uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
+                  int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t mstep_every, int64_t accumulate_from,
+                  int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);
 /* log p(f, r, b, bt; theta) of each chain = minus the first four terms of fit.py:149-152 at one-hot q.
  * out (G,) doubles. */
 int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,

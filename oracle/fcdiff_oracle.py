@@ -331,6 +331,87 @@ def vb_fit(b, bt, theta, max_iters=10, rel_tol=1e-5, mode=EDGE_REFERENCE, check_
 
 
 # ----------------------------------------------------------------------------------------
+# The same variational updates WITHOUT the Python loop over edges (CPU baseline mode (ii):
+# "vectorised NumPy ... the honest strong baseline").  Same arithmetic, whole-array expressions; pinned to the
+# edge-loop forms above by tests/test_oracle_golden.py.  bench.py times both beside the GPU iteration.
+# ----------------------------------------------------------------------------------------
+def update_lq_F_vec(lq_R, S_B, lM, gamma):
+    """fit.py:157-174 over all edges at once."""
+    ep = edge_endpoints(lq_R.shape[0])
+    (n, m) = (ep[:, 0], ep[:, 1])
+    with np.errstate(divide="ignore"):
+        q_R = np.exp(lq_R)
+    w = np.stack([q_R[n, :, 0] * q_R[m, :, 0], q_R[n, :, 1] * q_R[m, :, 1],
+                  q_R[n, :, 0] * q_R[m, :, 1] + q_R[n, :, 1] * q_R[m, :, 0]], axis=2)          # (C,U,3)
+    lq_F = (np.log(gamma)[None, :] + S_B + np.einsum("cul,cukl->ck", w, lM))[:, None, :]
+    return lq_F - logsumexp(lq_F, axis=2)
+
+
+def update_lq_R_vec(lq_R, lq_F, lM, pi2, mode=EDGE_REFERENCE):
+    """fit.py:176-198: regions still in order (Gauss-Seidel), each region's sum over (m, k) as array expressions."""
+    (Nreg, U) = lq_R.shape[0:2]
+    with np.errstate(divide="ignore"):
+        q_R = np.exp(lq_R)
+        q_F = np.exp(lq_F)[:, 0, :]
+        lnpi2 = np.log(np.asarray(pi2, dtype=np.float64))
+    out = np.zeros((Nreg, U, 2))
+    ms_all = np.arange(Nreg)
+    for n in range(Nreg):
+        ms = ms_all[ms_all != n]
+        cs = np.array([edge_id(n, int(mm), mode) for mm in ms])
+        t = lM[cs]                                           # (Nreg-1, U, 3, 3)
+        qf = q_F[cs][:, None, :]                             # (Nreg-1, 1, 3)
+        q0, q1 = q_R[ms, :, 0][:, :, None], q_R[ms, :, 1][:, :, None]
+        s0 = np.sum(qf * (q0 * t[:, :, :, 0] + q1 * t[:, :, :, 2]), axis=(0, 2))
+        s1 = np.sum(qf * (q1 * t[:, :, :, 1] + q0 * t[:, :, :, 2]), axis=(0, 2))
+        row = np.stack([lnpi2[0] + s0, lnpi2[1] + s1], axis=1)
+        row = row - logsumexp(row, axis=1)
+        out[n] = row
+        q_R[n] = np.exp(row)
+    return out
+
+
+def eval_E_lM_vec(q_F, q_R, lM):
+    ep = edge_endpoints(q_R.shape[0])
+    (n, m) = (ep[:, 0], ep[:, 1])
+    w = np.stack([q_R[n, :, 0] * q_R[m, :, 0], q_R[n, :, 1] * q_R[m, :, 1],
+                  q_R[n, :, 0] * q_R[m, :, 1] + q_R[n, :, 1] * q_R[m, :, 0]], axis=2)
+    return np.sum(q_F[:, 0, :] * np.einsum("cul,cukl->ck", w, lM))
+
+
+def vb_iteration(lq_F, lq_R, b, bt, th, mode=EDGE_REFERENCE, vectorised=False):
+    """
+    ONE iteration of the documented loop (doc/methods.rst:564-600; fit.py:75-82): q_F, q_R, pi / gamma, tables,
+    energy.  vectorised=False is the reference's structure (Python loop over edges, mode (i) of SURVEY.md section 8d),
+    True the whole-array form (mode (ii)).  Returns (lq_F, lq_R, th, energy).
+    """
+    th = dict(th)
+    lpB, _, lM = lik_tables(b, bt, th["mu"], th["sigma"], th["eta"], th["epsilon"])
+    S_B = sum_lp_B(lpB)
+    pi2 = [1 - th["pi"], th["pi"]]
+    if vectorised:
+        lq_F = update_lq_F_vec(lq_R, S_B, lM, th["gamma"])
+        lq_R = update_lq_R_vec(lq_R, lq_F, lM, pi2, mode)
+    else:
+        lq_F = update_lq_F(lq_R, S_B, lM, th["gamma"])
+        lq_R = update_lq_R(lq_R, lq_F, lM, pi2, mode)
+    th["pi"] = update_pi(lq_R)
+    th["gamma"] = update_gamma(lq_F)
+    lpB, _, lM = lik_tables(b, bt, th["mu"], th["sigma"], th["eta"], th["epsilon"])
+    S_B = sum_lp_B(lpB)
+    pi2 = [1 - th["pi"], th["pi"]]
+    if vectorised:
+        with np.errstate(divide="ignore"):
+            q_F, q_R = np.exp(lq_F), np.exp(lq_R)
+        t = [eval_E_lp_F(q_F, th["gamma"]), eval_E_lp_B_g_F(q_F, S_B), eval_E_lp_R(q_R, pi2), eval_E_lM_vec(q_F, q_R, lM),
+             eval_E_lq_F(q_F, lq_F), eval_E_lq_R(q_R, lq_R)]
+        e = -t[0] - t[1] - t[2] - t[3] + t[4] + t[5]
+    else:
+        e = eval_energy(lq_F, lq_R, S_B, lM, th["gamma"], pi2)
+    return lq_F, lq_R, th, e
+
+
+# ----------------------------------------------------------------------------------------
 # derivative helpers -- fcdiff/fit.py:542-733 (only the runnable module-level ones)
 # ----------------------------------------------------------------------------------------
 def eval_dlN_dm(b, mu, sigma):

@@ -58,6 +58,16 @@ class OracleEngine(object):
             self.accumulate()
         return self.stats() if want_counts else None
 
+    def run(self, sweep0, n_sweeps, mstep_every=0, accumulate_from=None, want_counts=False):
+        """Restatement of fcd_gibbs_run's contract (include/fcdiff_hip.h)."""
+        for j in range(n_sweeps):
+            self.sweeps(sweep0 + j, 1)
+            if accumulate_from is not None and sweep0 + j >= accumulate_from:
+                self.accumulate()
+            if mstep_every > 0 and (j + 1) % mstep_every == 0:
+                self.mstep(self.stats())
+        return self.stats() if want_counts else None
+
 
 def problem():
     g = load_golden("G11_gibbs_conditionals_cfg1")
@@ -66,14 +76,14 @@ def problem():
     return g["lp_B_g_F"].sum(axis=1), g["lM"], Nreg, U, th
 
 
-def run_single(total, n_sweeps, seed):
+def run_single(total, n_sweeps, seed, mstep_every=1, lag=0, on_sweep=None):
     (S_B, lM, Nreg, U, th) = problem()
     eng = OracleEngine(S_B, lM, Nreg, U, total, 0, seed, th["gamma"], th["pi"])
-    run_chains(eng, n_sweeps, mstep_every=1, burn_in=1)
+    run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, on_sweep=on_sweep)
     return eng
 
 
-def worker(rank, world, port, total, n_sweeps, seed, out_dir):
+def worker(rank, world, port, total, n_sweeps, seed, out_dir, mstep_every=1, lag=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,7 +91,7 @@ def worker(rank, world, port, total, n_sweeps, seed, out_dir):
         (S_B, lM, Nreg, U, th) = problem()
         (chain0, n_local) = shard_chains(total, world, rank)
         eng = OracleEngine(S_B, lM, Nreg, U, n_local, chain0, seed, th["gamma"], th["pi"])
-        run_chains(eng, n_sweeps, mstep_every=1, burn_in=1)
+        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag)
         cnt = torch.from_numpy(eng.cnt_r.copy())
         dist.all_reduce(cnt)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=eng.f, r=eng.r, pi=eng.pi, gamma=eng.gamma,
@@ -103,12 +113,34 @@ def test_shard_chains():
     assert tot == 8192
 
 
+def test_run_chains_schedules_on_one_rank():
+    """
+    One process: the single-call form, the per-sweep form (a callback forces chunks of one sweep) and a chunked
+    M-step cadence walk the same chains; the lagged schedule is a different (documented) trajectory of its own.
+    """
+    (total, n_sweeps, seed) = (6, 6, 5)
+    a = run_single(total, n_sweeps, seed, mstep_every=2)
+    seen = []
+    b = run_single(total, n_sweeps, seed, mstep_every=2, on_sweep=lambda i, e: seen.append(i))
+    assert seen == list(range(n_sweeps))
+    np.testing.assert_array_equal(a.f, b.f)
+    np.testing.assert_array_equal(a.r, b.r)
+    assert a.pi == b.pi and a.n_acc == b.n_acc == n_sweeps - 1
+    np.testing.assert_array_equal(a.cnt_r, b.cnt_r)
+    lag = run_single(total, n_sweeps, seed, mstep_every=2, lag=1)
+    lag2 = run_single(total, n_sweeps, seed, mstep_every=2, lag=1, on_sweep=lambda i, e: None)
+    np.testing.assert_array_equal(lag.r, lag2.r)
+    assert lag.pi == lag2.pi
+    assert not np.array_equal(lag.r, a.r) or not np.array_equal(lag.f, a.f)     # a different schedule, a different path
+
+
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_process(tmp_path):
+@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (2, 1)])
+def test_two_ranks_equal_one_process(tmp_path, mstep_every, lag):
     (total, n_sweeps, seed) = (9, 4, 77)
-    ref = run_single(total, n_sweeps, seed)
+    ref = run_single(total, n_sweeps, seed, mstep_every=mstep_every, lag=lag)
     port = free_port()
-    mp.spawn(worker, args=(2, port, total, n_sweeps, seed, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, port, total, n_sweeps, seed, str(tmp_path), mstep_every, lag), nprocs=2, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
     assert [int(p["chain0"]) for p in parts] == [0, 5]
     np.testing.assert_array_equal(np.concatenate([p["f"] for p in parts]), ref.f)

@@ -509,6 +509,44 @@ def test_gibbs_sweeps_driver_equals_separate_passes(env):
     nptest.assert_array_equal(states[0][1], states[1][1])
 
 
+@pytest.mark.parametrize("N,U,G,mode", [(45, 7, 200, "symmetric"), (18, 70, 64, "symmetric"), (33, 5, 130, "reference")])
+def test_gibbs_run_equals_call_by_call_loop(env, N, U, G, mode):
+    """
+    fcd_gibbs_run (one call: per sweep f pass, r pass and ONE tally launch that also carries the M-step and the packed
+    r words of the next f pass) against the same loop made of the separate entry points (f step, r step, tally,
+    M-step kernel): chains, hyper-parameters, marginal counters and pooled counts must be identical.  Shapes: several
+    blocks of regions with a partial chain word, the any-U f kernel, the reference edge ids (no square copy).
+    """
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + 2 * U)
+    (n_sweeps, burn) = (5, 2)
+    out = []
+    for fused in (True, False):
+        eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=8, seed=77, edge_index=mode, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.25)
+        if fused:
+            counts = eng.run(0, n_sweeps, mstep_every=2, accumulate_from=burn, want_counts=True).cpu().numpy().copy()
+        else:
+            for s in range(n_sweeps):
+                eng.f_step(s)
+                eng.r_step(s)
+                do_m = (s + 1) % 2 == 0
+                c = eng.tally(want_counts=True, accumulate=s >= burn)
+                if do_m:
+                    eng.mstep(c)
+            counts = eng.counts.cpu().numpy().copy()
+        (f, r) = eng.export_state()
+        out.append((f, r, eng.hyper.cpu().numpy().copy(), eng.cnt_f.cpu().numpy().copy(), eng.cnt_r.cpu().numpy().copy(),
+                    counts, eng.n_accumulated))
+    for (a, b_) in zip(out[0], out[1]):
+        nptest.assert_array_equal(a, b_)
+    assert out[0][6] == n_sweeps - burn
+    assert out[0][5][4] == G and out[0][5][5:].sum() == 0
+    # the context's accumulators are back at zero: a second tally gives the same counts again
+    again = eng.tally(want_counts=True, accumulate=False).cpu().numpy()
+    nptest.assert_array_equal(again, out[1][5])
+
+
 def test_gibbs_chain_sharding_invariance(env):
     """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
     (N, U, G) = (12, 6, 192)

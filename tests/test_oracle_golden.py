@@ -114,6 +114,33 @@ def test_G10_vb_trajectory(name, iters):
         nptest.assert_allclose(gamma, g["gamma"][i + 1], rtol=1e-11)
 
 
+def test_vectorised_forms_against_reference_fixtures():
+    """The whole-array restatements (bench.py's CPU baseline mode (ii)) against the reference's own outputs G4, G5, G6."""
+    g = load_golden("G4_update_lq_F")
+    lq_F = O.update_lq_F_vec(np.log(g["q_R"]), O.sum_lp_B(g["lp_B_g_F"]), g["lM"], g["gamma"])
+    nptest.assert_allclose(lq_F, g["lq_F"], rtol=1e-12)
+    g = load_golden("G5_update_lq_R")
+    lq_R = O.update_lq_R_vec(np.log(g["q_R"]), np.log(g["q_F"]), g["lM"], g["pi"], O.EDGE_REFERENCE)
+    nptest.assert_allclose(lq_R, g["lq_R"], rtol=1e-12)
+    g = load_golden("G6_energy_terms")
+    nptest.assert_allclose(O.eval_E_lM_vec(g["q_F"], g["q_R"], g["lM"]), g["terms"][3], rtol=1e-12)
+
+
+@pytest.mark.parametrize("vectorised", [False, True])
+def test_vb_iteration_walks_the_reference_trajectory(vectorised):
+    """vb_iteration (what bench.py times on the host, both modes) reproduces G10 iteration by iteration."""
+    g = load_golden("G10_vb_trajectory_cfg1")
+    th = theta_dict(g["theta0"])
+    (C, U) = (g["bt"].shape[0], g["bt"].shape[1])
+    N = int(O.C_to_N(C))
+    lq_R = np.full((N, U, 2), -np.log(2))
+    lq_F = np.full((C, 1, 3), -np.log(3))
+    for i in range(3):
+        (lq_F, lq_R, th, e) = O.vb_iteration(lq_F, lq_R, g["b"], g["bt"], th, vectorised=vectorised)
+        nptest.assert_allclose(e, g["energy"][i + 1], rtol=1e-11)
+        nptest.assert_allclose(lq_R, g["lq_R"][i], rtol=1e-9, atol=1e-11)
+
+
 def test_G10_survey_anchor():
     """SURVEY.md section 8c / BASELINE.md section 2 quote these three energies."""
     g = load_golden("G10_vb_trajectory_cfg1")
