@@ -55,6 +55,7 @@ SIGNATURES = {
     "fcd_theta_sub_weights_vb": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "fcd_gibbs_pair_counts": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p]),
     "fcd_theta_sub_objective": (_int, [_p, _p, _p, _i64, _i64, C.POINTER(_dbl), _p, _p]),
+    "fcd_theta_full_objective": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, C.POINTER(_dbl), _p, _p]),
     "fcd_gibbs_state_size": (_int, [_i64, _i64, _i64, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "fcd_gibbs_init": (_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _u64, _dbl, _p]),
     "fcd_gibbs_edge_tables": (_int, [_p, _p, _i64, _i64, _p, _p]),

@@ -123,6 +123,114 @@ __global__ __launch_bounds__(OBJ_BLOCK) void theta_sub_kernel(const double *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The FULL theta_sub objective the reference intends (commented out at fit.py:232-237, 250-251, 266-267, 282):
+//   S(eta, epsilon, mu, sigma^2) = E[ln p(b | f)] + E[ln p(bt | f, r)]
+//                               = sum_{c,k} wF[c,k] sum_h ln N(b_ch; mu_k, sigma_k) + sum W[c,u,k,l] ln M_kl(bt_cu)
+// with wF[c,k] = sum_l W[c,0,k,l] (= q_F[c,k], or the number of chains with f_c = k), and its gradient
+//   out9 = {S, dS/d eta, dS/d epsilon, dS/d mu_0..2, dS/d sigma^2_0..2}.
+// Derivative forms: d ln N/d mu = (b - mu)/sigma^2 (_eval_dlN_dm, fit.py:715-719), d ln N/d sigma^2 =
+// ((b - mu)^2 - sigma^2)/(2 sigma^4) -- the reference's _eval_dlN_ds (fit.py:727-733) is sigma^2 times this (the
+// derivative in ln sigma^2) --, dM_kl/d theta_j = (eps_l if j == k else (1 - eps_l)/2) dN_j/d theta_j (fit.py:700-707;
+// fit.py:572-597 has the same form up to quirk Q8; doc/methods.rst:715-944): the TRUE gradient of S, which is what
+// L-BFGS-B needs.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OBJ_BLOCK) void theta_full_kernel(const double *__restrict__ b, const double *__restrict__ bt,
+                                                               const double *__restrict__ W, int64_t C, int H, int U,
+                                                               SubTheta th, double *__restrict__ partial) {
+    __shared__ double red[OBJ_BLOCK / 64][9];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // S, gh, ge, gm[3], gs[3]
+    double s2[3], ls[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s2[k] = th.sigma[k] * th.sigma[k];
+        ls[k] = log(th.sigma[k]);
+    }
+    const int64_t n_bt = C * U;
+    for (int64_t i = (int64_t)blockIdx.x * OBJ_BLOCK + threadIdx.x; i < n_bt; i += (int64_t)gridDim.x * OBJ_BLOCK) {
+        const double x = bt[i];
+        double N[3], dNm[3], dNs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double d = x - th.mu[k];
+            const double z = d / th.sigma[k];
+            N[k] = exp(-(z * z) / 2.0) / kSqrt2Pi / th.sigma[k];                    // fit.py:115
+            dNm[k] = N[k] * (d / s2[k]);                                            // _eval_dN_dm
+            dNs[k] = N[k] * ((d * d - s2[k]) / (2.0 * s2[k] * s2[k]));              // d N / d sigma^2
+        }
+        const double others[3] = {N[1] + N[2], N[0] + N[2], N[0] + N[1]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double slope = N[k] - 0.5 * others[k];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const double w = W[i * 9 + k * 3 + l];
+                if (w != 0.0) {
+                    const double M = th.eps[l] * N[k] + (1 - th.eps[l]) * 0.5 * others[k];
+                    acc[0] += w * log(M);
+                    const double r = w / M;
+                    acc[2] += th.deps_de[l] * (r * slope);
+                    if (l == 2) acc[1] += th.deps_dh * (r * slope);
+                    const double co = 0.5 * (1 - th.eps[l]);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double cf = (j == k) ? th.eps[l] : co;
+                        acc[3 + j] += r * (cf * dNm[j]);
+                        acc[6 + j] += r * (cf * dNs[j]);
+                    }
+                }
+            }
+        }
+    }
+    if (b) {
+        const int64_t n_b = C * H;
+        for (int64_t i = (int64_t)blockIdx.x * OBJ_BLOCK + threadIdx.x; i < n_b; i += (int64_t)gridDim.x * OBJ_BLOCK) {
+            const int64_t c = i / H;
+            const double x = b[i];
+            const double *w0 = W + c * U * 9;              // patient 0 of the edge: sum over l = weight of f_c = k
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double wF = (w0[k * 3 + 0] + w0[k * 3 + 1]) + w0[k * 3 + 2];
+                if (wF != 0.0) {
+                    const double d = x - th.mu[k];
+                    const double z = d / th.sigma[k];
+                    acc[0] += wF * ((-(z * z) / 2.0 - 0.91893853320467274178) - ls[k]);     // norm.logpdf, fit.py:114
+                    acc[3 + k] += wF * (d / s2[k]);                                         // _eval_dlN_dm
+                    acc[6 + k] += wF * ((d * d - s2[k]) / (2.0 * s2[k] * s2[k]));
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const double v = fcd_wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double t = 0.0;
+        for (int q = 0; q < OBJ_BLOCK / 64; ++q) t += red[q][threadIdx.x];
+        partial[(int64_t)blockIdx.x * 12 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void theta_full_fold(const double *__restrict__ partial, int n_blocks, double *__restrict__ out9) {
+    __shared__ double red[4][9];
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bl = threadIdx.x; bl < n_blocks; bl += 256)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] += partial[(int64_t)bl * 12 + j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const double s = fcd_wave_sum(v[j]);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) out9[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void theta_sub_fold(const double *__restrict__ partial, int n_blocks, double *__restrict__ out3) {
     __shared__ double red[4][3];
     double v[3] = {0, 0, 0};
@@ -197,6 +305,42 @@ extern "C" int fcd_theta_sub_objective(fcd_ctx *ctx, const double *bt, const dou
     hipLaunchKernelGGL(theta_sub_kernel, dim3((unsigned)blocks), dim3(OBJ_BLOCK), 0, s, bt, W, n_items, th, (double *)ctx->ws);
     FCD_LAUNCH_CHECK();
     hipLaunchKernelGGL(theta_sub_fold, dim3(1), dim3(256), 0, s, (const double *)ctx->ws, (int)blocks, out3);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_theta_full_objective(fcd_ctx *ctx, const double *b, const double *bt, const double *W, int64_t C, int64_t H,
+                                        int64_t U, const double *theta, double *out9, fcd_stream stream) {
+    if (!ctx || !bt || !W || !theta || !out9) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_theta_full_objective: null pointer");
+    if (C < 1 || U < 1 || (b && H < 1) || H > INT32_MAX || U > INT32_MAX)
+        return fcd_fail(ctx, FCD_ERR_ARG, "fcd_theta_full_objective: C=%lld U=%lld must be >= 1", C, U);
+    SubTheta th;
+    const double eta = theta[1], epsilon = theta[2];
+    for (int k = 0; k < 3; ++k) {
+        th.mu[k] = theta[6 + k];
+        th.sigma[k] = theta[9 + k];
+        if (!(th.sigma[k] > 0.0)) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_theta_full_objective: sigma must be positive");
+    }
+    th.eps[0] = 1 - epsilon;                       // _eval_M_eps, fit.py:433-444
+    th.eps[1] = epsilon;
+    double e2 = eta * epsilon;
+    e2 += (1 - eta) * (1 - epsilon);
+    th.eps[2] = e2;
+    th.deps_de[0] = -1;
+    th.deps_de[1] = 1;
+    th.deps_de[2] = 2 * eta - 1;
+    th.deps_dh = (2 * epsilon) - 1;
+    const int64_t n_items = C * (U > H ? U : H);
+    int64_t blocks = (n_items + OBJ_BLOCK - 1) / OBJ_BLOCK;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    int rc = fcd_ws_reserve(ctx, (size_t)blocks * 12 * sizeof(double));
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(theta_full_kernel, dim3((unsigned)blocks), dim3(OBJ_BLOCK), 0, s, b, bt, W, C, (int)H, (int)U, th,
+                       (double *)ctx->ws);
+    FCD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(theta_full_fold, dim3(1), dim3(256), 0, s, (const double *)ctx->ws, (int)blocks, out9);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

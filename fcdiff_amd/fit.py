@@ -57,6 +57,7 @@ class UnsharedRegionFit(object):
         self.method = "vb"
         self.edge_index = None
         self.update_theta_sub = False
+        self.theta_sub_params = "eta_epsilon"     # 'all': mu and sigma^2 join the optimiser (the reference's commented-out intent)
         self.n_chains = 1024
         self.n_sweeps = 100
         self.burn_in = 20
@@ -404,10 +405,19 @@ class UnsharedRegionFit(object):
         (1e-5, 1 - 1e-5) on both, L-BFGS-B.  The reference's version cannot run (it calls the undefined `opt_fun`,
         fit.py:239) and would difference the objective numerically (`jac=False`); here objective AND its two analytic
         derivatives (the formulas of `_eval_dE_dh` / `_eval_dE_de`, fit.py:600-697) come from one kernel pass over bt.
-        mu and sigma stay fixed, as in the reference (commented out of its optimiser, fit.py:232-237, 250-251).
+        theta_sub_params = 'eta_epsilon' (default): mu and sigma stay fixed, as in the reference as shipped (commented
+        out of its optimiser, fit.py:232-237, 250-251); 'all' reads those lines in: (eta, epsilon, mu, sigma^2) jointly,
+        objective E[ln p(b|f)] + E[ln p(bt|f,r)] (fit.py:282), fcd_theta_full_objective.
         """
         W = self._theta_sub_weights()
-        (eta, epsilon, info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model)
+        if self.theta_sub_params == "all":
+            # the reference's commented-out intent (fit.py:232-237, 250-251, 266-267, 282): mu and sigma too
+            (eta, epsilon, mu, sigma, info) = minimize_theta_full(self._context(), self._d["b"], self._d["bt"], W, self.model)
+            self.model.mu, self.model.sigma = mu, sigma
+        elif self.theta_sub_params == "eta_epsilon":
+            (eta, epsilon, info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model)
+        else:
+            raise ValueError("theta_sub_params must be 'eta_epsilon' or 'all'")
         self.model.eta, self.model.epsilon = eta, epsilon
         self._theta_sub_info = info
 
@@ -451,8 +461,13 @@ class UnsharedRegionFit(object):
             if self.update_theta_sub and self.theta_sub_every and (i + 1) % self.theta_sub_every == 0 and i + 1 < self.n_sweeps:
                 # Monte-Carlo EM for (eta, epsilon): pooled counts of (f_c, mixture case) over all chains of all ranks
                 W = e.pair_counts()
-                (eta, epsilon, _info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model,
-                                                           reduce=allreduce_counts)
+                if self.theta_sub_params == "all":
+                    (eta, epsilon, mu, sigma, _info) = minimize_theta_full(self._context(), self._d["b"], self._d["bt"], W,
+                                                                           self.model, reduce=allreduce_counts)
+                    self.model.mu, self.model.sigma = mu, sigma
+                else:
+                    (eta, epsilon, _info) = minimize_theta_sub(self._context(), self._d["bt"], W, self.model,
+                                                               reduce=allreduce_counts)
                 self.model.eta, self.model.epsilon = eta, epsilon
                 self._update_lps()            # tables follow theta_sub ...
                 e.refresh_tables()            # ... and so do the sampler's two difference tables
@@ -489,6 +504,56 @@ def theta_sub_objective(ctx, bt_dev, W, theta, reduce=None):
     if reduce is not None:
         out = reduce(out)
     return out.cpu().numpy()
+
+
+def theta_full_objective(ctx, b_dev, bt_dev, W, theta, reduce=None):
+    """
+    {S, dS/d eta, dS/d epsilon, dS/d mu[3], dS/d sigma^2[3]} of the full theta_sub objective (fcd_theta_full_objective):
+    S = E[ln p(b | f)] + E[ln p(bt | f, r)] for the weights W.  `reduce` sums the nine numbers over ranks.
+    With several ranks each rank's W holds its own chain counts, but b is the same on all: pass b_dev on every rank
+    (the healthy term scales with the chain counts too, so the sum over ranks is the pooled objective).
+    """
+    import torch
+    out = torch.empty(9, dtype=torch.float64, device=W.device)
+    (th, _th) = _lib.dbl_array(theta)
+    H = int(b_dev.shape[1]) if b_dev is not None else 0
+    ctx.call("fcd_theta_full_objective", _lib.dptr(b_dev), _lib.dptr(bt_dev), _lib.dptr(W), int(W.shape[0]), H,
+             int(W.shape[1]), th, _lib.dptr(out), _lib.stream_ptr())
+    if reduce is not None:
+        out = reduce(out)
+    return out.cpu().numpy()
+
+
+def minimize_theta_full(ctx, b_dev, bt_dev, W, model, reduce=None, bound_eps=1e-5):
+    """
+    argmin of -(E[ln p(b | f)] + E[ln p(bt | f, r)]) over theta_sub = (eta, epsilon, mu[3], sigma^2[3]): the step the
+    reference intends (fit.py:222-286 with its commented-out lines read in): pack order and sigma ** 2 as in
+    fit.py:243-252, bounds of fit.py:228-237 -- eta, epsilon in (e, 1-e), mu_0 in (-1+e, -e), mu_1 in (-e, e), mu_2 in
+    (e, 1-e), sigma^2 > e --, analytic gradient, L-BFGS-B.  Returns (eta, epsilon, mu, sigma, scipy result).
+    """
+    import scipy.optimize as spopt
+    base = np.array(model.theta(), dtype=np.float64)
+    e = bound_eps
+
+    def unpack(x):
+        th = base.copy()
+        th[1], th[2] = float(x[0]), float(x[1])
+        th[6:9] = x[2:5]
+        th[9:12] = np.sqrt(x[5:8])
+        return th
+
+    def fun(x):
+        o = theta_full_objective(ctx, b_dev, bt_dev, W, unpack(x), reduce)
+        return (-o[0], -o[1:9])
+    bnds = ((e, 1 - e), (e, 1 - e), (-1 + e, 0 - e), (0 - e, 0 + e), (0 + e, 1 - e), (0 + e, None), (0 + e, None), (0 + e, None))
+    x0 = np.concatenate([[model.eta, model.epsilon], np.asarray(model.mu, dtype=np.float64),
+                         np.asarray(model.sigma, dtype=np.float64) ** 2])
+    lo = np.array([bd[0] for bd in bnds])
+    hi = np.array([np.inf if bd[1] is None else bd[1] for bd in bnds])
+    x0 = np.minimum(np.maximum(x0, lo), hi)
+    res = spopt.minimize(fun, x0, jac=True, bounds=bnds, method="L-BFGS-B")
+    th = unpack(res.x)
+    return float(th[1]), float(th[2]), th[6:9].copy(), th[9:12].copy(), res
 
 
 def minimize_theta_sub(ctx, bt_dev, W, model, reduce=None, bound_eps=1e-5):

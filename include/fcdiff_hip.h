@@ -162,6 +162,15 @@ int fcd_gibbs_pair_counts(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *
                           int64_t G, int accumulate, double *W, fcd_stream stream);
 int fcd_theta_sub_objective(fcd_ctx *ctx, const double *bt, const double *W, int64_t C, int64_t U,
                             const double *theta12_host, double *out3, fcd_stream stream);
+/* The FULL theta_sub objective the reference intends but comments out (fit.py:232-237 bounds, :250-251 / :266-267 pack
+ * and unpack of mu and sigma^2, :282 the E[ln p(b | f)] term):
+ *   S = sum_{c,k} wF[c,k] sum_h ln N(b[c,h]; mu_k, sigma_k) + sum W[c,u,k,l] ln M_kl(bt[c,u]),   wF[c,k] = sum_l W[c,0,k,l]
+ * out9 = {S, dS/d eta, dS/d epsilon, dS/d mu_0..2, dS/d (sigma^2)_0..2} (device): the true gradient of S in the
+ * reference's own parametrisation (it packs sigma ** 2).  Forms: fit.py:542-569, 572-597 (without quirk Q8, which
+ * lives in a helper the objective never calls), 709-733; doc/methods.rst:715-944.  b == NULL leaves the first sum out.
+ * Deterministic. */
+int fcd_theta_full_objective(fcd_ctx *ctx, const double *b, const double *bt, const double *W, int64_t C, int64_t H,
+                             int64_t U, const double *theta12_host, double *out9, fcd_stream stream);
 
 /* ---- many-chain collapsed Gibbs sampler ---------------------------------------------------
  * Build-defined (the reference ships only the variational fitter, doc/methods.rst:236-239).  Its two

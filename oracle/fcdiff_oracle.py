@@ -734,6 +734,41 @@ def theta_sub_objective(bt, W, mu, sigma, eta, epsilon):
     return S, dh, de
 
 
+def theta_full_objective(b, bt, W, mu, sigma, eta, epsilon):
+    """
+    The full theta_sub objective the reference comments out (fit.py:232-237, 250-251, 266-267, 282) and its gradient:
+        S = sum_{c,k} wF[c,k] sum_h ln N(b_ch; mu_k, sigma_k) + sum W[c,u,k,l] ln M_kl(bt_cu),  wF[c,k] = sum_l W[c,0,k,l]
+    Returns (S, dS/d eta, dS/d epsilon, dS/d mu (3,), dS/d sigma^2 (3,)).  Built from the reference's helper forms (pinned
+    by fixture G8): eval_dlN_dm / eval_dN_dm (fit.py:709-719), eval_dlN_ds / eval_dN_ds (fit.py:721-733) -- the latter
+    are sigma^2 times the derivative in sigma^2 (i.e. the derivative in ln sigma^2), hence the division below -- and the
+    coefficient of fit.py:700-707: eps_l for j == k, (1 - eps_l)/2 otherwise.  b=None leaves the first sum out.
+    """
+    (C, U) = bt.shape
+    mu, sigma = np.asarray(mu, dtype=np.float64), np.asarray(sigma, dtype=np.float64)
+    norm = np.zeros((C, U, 3))
+    for k in range(3):
+        norm[:, :, k] = norm_pdf(bt, mu[k], sigma[k])
+    (S, dh, de) = theta_sub_objective(bt, W, mu, sigma, eta, epsilon)
+    dm, ds = np.zeros(3), np.zeros(3)
+    for k in range(3):
+        for l in range(3):
+            M = eval_M(norm, eta, epsilon, k, l)
+            w = W[:, :, k, l]
+            nz = w != 0
+            e = eval_M_eps(eta, epsilon, l)
+            for j in range(3):
+                cf = e if j == k else (1 - e) / 2
+                dm[j] += np.sum((w * cf * eval_dN_dm(norm[:, :, j], bt, mu[j], sigma[j]) / M)[nz])
+                ds[j] += np.sum((w * cf * eval_dN_ds(norm[:, :, j], bt, mu[j], sigma[j]) / M)[nz]) / (sigma[j] * sigma[j])
+    if b is not None:
+        wF = np.sum(W[:, 0, :, :], axis=2)                  # (C, 3)
+        for k in range(3):
+            S += np.sum(wF[:, k] * np.sum(norm_logpdf(b, mu[k], sigma[k]), axis=1))
+            dm[k] += np.sum(wF[:, k] * np.sum(eval_dlN_dm(b, mu[k], sigma[k]), axis=1))
+            ds[k] += np.sum(wF[:, k] * np.sum(eval_dlN_ds(b, mu[k], sigma[k]), axis=1)) / (sigma[k] * sigma[k])
+    return S, dh, de, dm, ds
+
+
 def pair_counts(f, r):
     """(C,U,3,3) counts over chains of (f_c, mixture case at (c,u))."""
     (G, C) = f.shape

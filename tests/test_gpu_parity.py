@@ -859,6 +859,101 @@ def test_vb_run_with_theta_sub(env):
     assert len(full.energy) == 4 and np.all(np.isfinite(full.energy))
 
 
+def test_theta_full_objective_against_oracle_and_differences(env):
+    """
+    The full theta_sub objective (mu and sigma^2 beside eta, epsilon; SURVEY section 8f item 1, second half): the kernel's
+    nine numbers against the oracle's composition of the reference's derivative helpers (pinned by fixture G8:
+    _eval_dlN_dm / _eval_dN_dm fit.py:709-719, _eval_dlN_ds / _eval_dN_ds fit.py:721-733, coefficient of fit.py:700-707),
+    for VB weights and for chain counts, with and without the healthy-subject term -- and against central differences
+    of the objective itself in all eight parameters.
+    """
+    from fcdiff_amd.fit import theta_full_objective
+    (N, H, U) = (9, 4, 7)
+    m = env.pkg.UnsharedRegionModel()
+    m.eta, m.epsilon = 0.29, 0.07
+    m.mu, m.sigma = np.array([-0.2, 0.01, 0.33]), np.array([0.06, 0.08, 0.11])
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=3)
+    C = N * (N - 1) // 2
+    rs = np.random.RandomState(5)
+    q_F = rs.uniform(1e-7, 1, (C, 1, 3))
+    q_F /= q_F.sum(axis=2, keepdims=True)
+    q_R = rs.uniform(1e-7, 1, (N, U, 2))
+    q_R /= q_R.sum(axis=2, keepdims=True)
+    W_vb = env.O.vb_weights(q_F, q_R)
+    f = rs.randint(0, 3, (70, C)).astype(np.uint8)
+    r = (rs.rand(70, N, U) < 0.3).astype(np.uint8)
+    W_ct = env.O.pair_counts(f, r)                               # zeros inside: the w != 0 guards are exercised
+    (b_d, bt_d) = (up(env, b), up(env, bt))
+    for W in (W_vb, W_ct):
+        W_d = up(env, W)
+        for with_b in (True, False):
+            got = theta_full_objective(env.ctx, b_d if with_b else None, bt_d, W_d, m.theta())
+            (S, dh, de, dm, ds) = env.O.theta_full_objective(b if with_b else None, bt, W, m.mu, m.sigma, m.eta, m.epsilon)
+            nptest.assert_allclose(got, np.concatenate([[S, dh, de], dm, ds]), rtol=1e-10)
+    # the first three numbers without b are fcd_theta_sub_objective's
+    from fcdiff_amd.fit import theta_sub_objective
+    W_d = up(env, W_vb)
+    nptest.assert_allclose(theta_full_objective(env.ctx, None, bt_d, W_d, m.theta())[:3],
+                           theta_sub_objective(env.ctx, bt_d, W_d, m.theta()), rtol=1e-12)
+    # gradient = derivative of the objective: theta index -> (out9 index, step through sigma^2 for the last three)
+    base = np.array(m.theta())
+    g = theta_full_objective(env.ctx, b_d, bt_d, W_d, base)
+
+    def S_at(x8):
+        th = base.copy()
+        th[1], th[2], th[6:9], th[9:12] = x8[0], x8[1], x8[2:5], np.sqrt(x8[5:8])
+        return theta_full_objective(env.ctx, b_d, bt_d, W_d, th)[0]
+    x = np.concatenate([[m.eta, m.epsilon], m.mu, m.sigma ** 2])
+    for i in range(8):
+        h = 1e-6 * max(abs(x[i]), 1e-2)
+        (xp, xm) = (x.copy(), x.copy())
+        xp[i] += h
+        xm[i] -= h
+        nptest.assert_allclose(g[1 + i], (S_at(xp) - S_at(xm)) / (2 * h), rtol=2e-6)
+
+
+def test_vb_theta_sub_step_with_mu_sigma(env):
+    """
+    _update_theta_sub with theta_sub_params='all' (the reference's commented-out intent, fit.py:232-237, 250-251,
+    266-267, 282): the free energy after the step is not above the one before it, the parameters respect the
+    reference's bounds, and mu / sigma move towards the planted values from a perturbed start.
+    """
+    (N, H, U) = (12, 8, 10)
+    gen = env.pkg.UnsharedRegionModel()
+    gen.pi, gen.eta, gen.epsilon = 0.15, 0.6, 0.08
+    gen.gamma, gen.mu, gen.sigma = np.ones(3) / 3, np.array([-0.5, 0, 0.5]), np.ones(3) * 0.05
+    (r, t, f, ft, b, bt) = gen.sample_fast(N, H, U, seed=2)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.edge_index = b, bt, "symmetric"
+    fit.model = make_model(env, gen.theta())
+    fit.model.eta, fit.model.epsilon = 0.3, 0.02
+    fit.model.mu, fit.model.sigma = np.array([-0.42, 0.004, 0.43]), np.array([0.08, 0.07, 0.09])
+    fit.theta_sub_params = "all"
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    fit._update_lq_F()
+    fit._update_lq_R()
+    e0 = fit._eval_energy()
+    fit._update_theta_sub()
+    assert fit._theta_sub_info.success or fit._theta_sub_info.status in (0, 1, 2)
+    fit._update_lps()
+    e1 = fit._eval_energy()
+    assert e1 <= e0 + 1e-9 * abs(e0)
+    (mu, sg) = (np.asarray(fit.model.mu), np.asarray(fit.model.sigma))
+    e = 1e-5
+    assert -1 + e <= mu[0] <= -e and -e <= mu[1] <= e and e <= mu[2] <= 1 - e and np.all(sg ** 2 >= e)   # fit.py:232-237
+    assert abs(mu[0] + 0.5) < 0.08 - 0.02 and abs(mu[2] - 0.5) < 0.07 - 0.02
+    assert np.all(np.abs(sg - 0.05) < np.abs(np.array([0.08, 0.07, 0.09]) - 0.05))
+    # the whole loop with the full step
+    full = new_fit(env)
+    full.b, full.bt, full.edge_index, full.update_theta_sub, full.theta_sub_params = b, bt, "symmetric", True, "all"
+    full.model = make_model(env, gen.theta())
+    full.model.mu, full.model.sigma = np.array([-0.42, 0.004, 0.43]), np.array([0.08, 0.07, 0.09])
+    full.rel_tol, full.max_iters = -np.inf, 3
+    full.run()
+    assert len(full.energy) == 4 and np.all(np.isfinite(full.energy)) and full.energy[-1] <= full.energy[1]
+
+
 def test_model_sample_gpu_statistics(env):
     """Device forward sampler: the statistical checks of test_fcdiff/test_model.py."""
     m = env.pkg.UnsharedRegionModel()
