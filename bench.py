@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 LDS_CLOCK_GHZ = 2.4          # MI355X peak engine clock
 LDS_BYTES_PER_CLK_CU = 256   # MI355X_MICROARCH.md, LDS: 64 dwords per clock and CU
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured float4 copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64, dense: datasheet figure; profiles/micro/mfma64.hip measures it on the box
 
 
 def main():
@@ -54,6 +55,8 @@ def main():
                          "(auto: 1 with several ranks, 0 with one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vb", action="store_true", help="skip the variational-iteration comparison")
+    ap.add_argument("--no-corr", action="store_true", help="skip the time-series front-end (K_corr)")
+    ap.add_argument("--timepoints", type=int, default=1200)
     ap.add_argument("--cpu-chains", type=int, default=0)
     args = ap.parse_args()
 
@@ -265,6 +268,32 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_vb:
         out["vb_iteration"] = vb_iteration(np, torch, fcdiff_amd, model, b, bt, Nreg, H, U, cfg_name)
+
+    if rank == 0 and world == 1 and not args.no_corr:
+        # K_corr, the front-end north_star names: (S, Nreg, T) time series -> edge-major correlations, fp64 MFMA Gram
+        from fcdiff_amd.corr import correlations
+        (S_all, T) = (H + U, args.timepoints)
+        ts = torch.randn((S_all, Nreg, T), dtype=torch.float64, device="cuda")
+        correlations(ts, ctx=ctx, as_numpy=False)
+        torch.cuda.synchronize()
+        n_rep = 5
+        tcr = time.perf_counter()
+        for _ in range(n_rep):
+            correlations(ts, ctx=ctx, as_numpy=False)
+        torch.cuda.synchronize()
+        corr_ms = (time.perf_counter() - tcr) / n_rep * 1e3
+        flops_full = 2.0 * S_all * Nreg * Nreg * T                       # SURVEY 8d convention (full product; SYRK does half)
+        flops_syrk = 2.0 * S_all * (Nreg * (Nreg + 1) / 2) * T
+        corr_bytes = 8 * S_all * Nreg * T + 8 * C * S_all
+        out["corr"] = {"kernel": "corr_gram_kernel (+ corr_moments_kernel)", "bound": "mfma", "dtype": "f64",
+                       "workload": "S=%d subjects, Nreg=%d, T=%d" % (S_all, Nreg, T), "ms": corr_ms,
+                       "flops_full_product": flops_full, "flops_lower_triangle": flops_syrk,
+                       "achieved": flops_syrk / (corr_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops_syrk / (corr_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                       "hbm_GBps": corr_bytes / (corr_ms * 1e-3) / 1e9, "hbm_frac": corr_bytes / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "both launches of fcd_corr_edges, wall time of %d calls; flops counted for the lower triangle "
+                               "actually needed; the input is read twice (moments, Gram)" % n_rep}
+        del ts
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle as CO

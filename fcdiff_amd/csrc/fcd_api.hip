@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "fcd_common.h"
+#include "fcd_fastmath.h"
 
 #ifdef FCD_ABLATE
 __device__ int fcd_abl_level[4];
@@ -170,19 +171,12 @@ int fcd_ctx_create(fcd_ctx **out) {
         return rc;
     }
     {
-        // table of K_lik's log: cell i = top 6 mantissa bits of the [1,2)-normalised argument; cells 32..63 are
-        // halved into [0.75, 1); the two cells around 1 use m_i = 1 (no cancellation near 1)
-        double tab[128];
-        for (int i = 0; i < 64; ++i) {
-            double m = 1.0 + (i + 0.5) / 64.0;
-            if (i >= 32) m *= 0.5;
-            if (i == 0 || i == 63) m = 1.0;
-            tab[i] = 1.0 / m;
-            tab[64 + i] = -log(tab[i]);      // log of the ROUNDED reciprocal's inverse: the identity stays exact
-        }
-        hipError_t e = hipMalloc(&ctx->log_tab, sizeof(tab));
+        // tables of K_lik's exp and log (fcd_fastmath.h): 2^(-j/64) and {1/m_i, log m_i}, made with the host's libm
+        struct { double exp_tab[FCD_EXP_CELLS]; fcd_log_cell log_tab[FCD_LOG_CELLS]; } tabs;
+        fcd_fm_make_tables(tabs.exp_tab, tabs.log_tab, exp2, log);
+        hipError_t e = hipMalloc(&ctx->log_tab, sizeof(tabs));
         ctx->n_alloc += 1;
-        if (e == hipSuccess) e = hipMemcpy(ctx->log_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ctx->log_tab, &tabs, sizeof(tabs), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&ctx->acc, 8 * sizeof(unsigned long long));
         ctx->n_alloc += 1;
         if (e == hipSuccess) e = hipMemset(ctx->acc, 0, 8 * sizeof(unsigned long long));

@@ -38,7 +38,7 @@ struct fcd_ctx {
     fcd_knobs knobs;
     long long n_alloc;             // device allocations made by this context so far (fcd_ctx_stat "n_alloc")
     size_t lds_attr[FCD_KA_N];     // largest dynamic-LDS size already set per kernel
-    void *log_tab;     // 64 x {1/m_i, log m_i} for the table-driven log of K_lik (device, 1 KiB)
+    void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass

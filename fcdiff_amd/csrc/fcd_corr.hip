@@ -7,8 +7,8 @@
 //
 // numpy.corrcoef, restated:  X -= mean(X, axis=1);  c = (X X^T) * (1/(T-1));  s = sqrt(diag c);
 //                            c /= s[:, None];  c /= s[None, :];  clip to [-1, 1].
-// The Gram matrix is an fp64 MFMA product (v_mfma_f64_16x16x4_f64): one wave per 16x16 tile of the lower
-// triangle, K = T in steps of 4.  Output out[c][s], c = n(n-1)/2 + m (n > m): the layout of b / bt.
+// The Gram matrix is an fp64 MFMA product (v_mfma_f64_16x16x4_f64) over 64 x 64 blocks of the lower triangle with
+// LDS-staged, double-buffered 64 x 16 panels.  Output out[c][s], c = n(n-1)/2 + m (n > m): the layout of b / bt.
 #include "fcd_common.h"
 
 namespace {
@@ -38,47 +38,117 @@ __global__ __launch_bounds__(256) void corr_moments_kernel(const double *__restr
     }
 }
 
-// grid = (lower-triangle tiles, subjects); block = one wave.
-// A[i][k] = xc[16 I + i][k0 + k] sits in lane (i = l & 15, k = l >> 4); B[k][j] = xc[16 J + j][k0 + k] in lane
-// (j = l & 15, k = l >> 4); D[i][j] comes back as 4 doubles per lane: col = l & 15, row = (l >> 4) + 4 r.
-__global__ __launch_bounds__(64) void corr_tiles_kernel(const double *__restrict__ ts, const double *__restrict__ mean,
+// Gram blocks.  grid = (lower-triangle blocks of 64 x 64 regions, subjects); block = 4 waves, wave (wr, wc) owns the
+// 2 x 2 MFMA tiles (2 wr + {0,1}, 2 wc + {0,1}) of the block.  K = T in steps of 16: the two 64 x 16 panels (rows of the
+// block's row regions / column regions, centred on the way in) are staged in LDS -- 128 contiguous bytes per region and
+// step, each element loaded once per block instead of once per tile -- double-buffered so that the loads of step k+1 fly
+// while the 16 MFMAs per wave of step k run.  Panel rows are padded to 18 doubles: the fragment reads (lane = (row i,
+// k-quarter q): P[16 t + i][4 g + q]) then fall on 32 distinct bank pairs.
+// Fragments of v_mfma_f64_16x16x4_f64: A[i][k] in lane (i = l & 15, k = l >> 4); B[k][j] in lane (j = l & 15, k = l >> 4);
+// D[i][j] comes back as 4 doubles per lane: col = l & 15, row = (l >> 4) + 4 r.
+constexpr int CB = 64, CK = 16, CLD = 18;
+__global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict__ ts, const double *__restrict__ mean,
                                                         const double *__restrict__ sdev, int Nreg, int T, int64_t S,
                                                         int fisher_z, double *__restrict__ out) {
-    // tile index -> (I, J), I >= J, lower-triangular row-major like the edges themselves
+    __shared__ double pa[2][CB * CLD], pb[2][CB * CLD];
+    // block index -> (I, J), I >= J, lower-triangular row-major like the edges themselves
     const int t = blockIdx.x;
     int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((int64_t)I * (I + 1) / 2 > t) --I;
     while ((int64_t)(I + 1) * (I + 2) / 2 <= t) ++I;
     const int J = t - I * (I + 1) / 2;
+    const bool diag = I == J;
     const int64_t s = blockIdx.y;
-    const int l = threadIdx.x;
-    const int ra = I * 16 + (l & 15), rb = J * 16 + (l & 15), kq = l >> 4;
-    const bool va = ra < Nreg, vb = rb < Nreg;
-    const double *xa = ts + (s * Nreg + (va ? ra : 0)) * T;
-    const double *xb = ts + (s * Nreg + (vb ? rb : 0)) * T;
-    const double ma = va ? mean[s * Nreg + ra] : 0.0, mb = vb ? mean[s * Nreg + rb] : 0.0;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < T; k0 += 4) {
-        const int k = k0 + kq;
-        const bool vk = k < T;
-        const double a = (va && vk) ? xa[k] - ma : 0.0;
-        const double b = (vb && vk) ? xb[k] - mb : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    // staging: thread -> (row of the panel, quarter of the 16 k): 4 doubles per panel and step
+    const int prow = tid >> 2, pq = tid & 3;
+    const int ga = I * CB + prow, gb = J * CB + prow;
+    const bool va = ga < Nreg, vb = gb < Nreg && !diag;
+    const double *xa = ts + (s * Nreg + (va ? ga : 0)) * T;
+    const double *xb = ts + (s * Nreg + (vb ? gb : 0)) * T;
+    const double ma = va ? mean[s * Nreg + ga] : 0.0, mb = vb ? mean[s * Nreg + gb] : 0.0;
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + pq * 4 + q;
+            const int kc = k < T ? k : T - 1;                  // clamped: no branch around the load
+            const double a = xa[kc], b = xb[kc];
+            ra[q] = (va && k < T) ? a - ma : 0.0;
+            rb[q] = (vb && k < T) ? b - mb : 0.0;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pa[buf][prow * CLD + pq * 4 + q] = ra[q];
+            if (!diag) pb[buf][prow * CLD + pq * 4 + q] = rb[q];
+        }
+    };
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // tiles of this wave that hold anything: rows below Nreg, and (diagonal block) not strictly above the diagonal
+    const int i16 = l & 15, kq = l >> 4;
+    bool on[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int tr = 2 * wr + a, tc = 2 * wc + b;
+            on[a][b] = (I * CB + tr * 16 < Nreg) && (J * CB + tc * 16 < Nreg) && (!diag || tc <= tr);
+        }
+    const bool any_on = on[0][0] || on[0][1] || on[1][0] || on[1][1];
+    fetch(0);
+    put(0);
+    __syncthreads();
+    const int steps = (T + CK - 1) / CK;
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) fetch((st + 1) * CK);
+        if (any_on) {
+            const double *A = pa[cur];
+            const double *B = diag ? pa[cur] : pb[cur];
+#pragma unroll
+            for (int g = 0; g < CK / 4; ++g) {
+                double fa[2], fb[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a] = A[((2 * wr + a) * 16 + i16) * CLD + g * 4 + kq];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fb[b] = B[((2 * wc + b) * 16 + i16) * CLD + g * 4 + kq];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (on[a][b]) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (st + 1 < steps) put(cur ^ 1);
+        __syncthreads();
     }
     const double inv = 1.0 / (double)(T - 1);
-    const int m = J * 16 + (l & 15);                      // column = the smaller region index of the pair
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = I * 16 + (l >> 4) + 4 * r;          // row
-        if (n < Nreg && m < n) {
-            double c = acc[r] * inv;
-            c /= sdev[s * Nreg + n];
-            c /= sdev[s * Nreg + m];
-            c = fmin(fmax(c, -1.0), 1.0);
-            if (fisher_z) c = atanh(c);
-            out[(fcd_tri(n) + m) * S + s] = c;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (!on[a][b]) continue;
+            const int m = J * CB + (2 * wc + b) * 16 + i16;                  // column = the smaller region index of the pair
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = I * CB + (2 * wr + a) * 16 + kq + 4 * r;       // row
+                if (n < Nreg && m < n) {
+                    double c = acc[a][b][r] * inv;
+                    c /= sdev[s * Nreg + n];
+                    c /= sdev[s * Nreg + m];
+                    c = fmin(fmax(c, -1.0), 1.0);
+                    if (fisher_z) c = atanh(c);
+                    out[(fcd_tri(n) + m) * S + s] = c;
+                }
+            }
         }
-    }
 }
 
 }  // namespace
@@ -95,9 +165,9 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_moments_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ts, rows, (int)T, mean, sdev);
     FCD_LAUNCH_CHECK();
-    const int64_t nt = (Nreg + 15) / 16;
-    const int64_t tiles = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(corr_tiles_kernel, dim3((unsigned)tiles, (unsigned)S), dim3(64), 0, s, ts, mean, sdev, (int)Nreg, (int)T, S,
+    const int64_t nb = (Nreg + CB - 1) / CB;
+    const int64_t blocks = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(corr_gram_kernel, dim3((unsigned)blocks, (unsigned)S), dim3(256), 0, s, ts, mean, sdev, (int)Nreg, (int)T, S,
                        fisher_z ? 1 : 0, out);
     FCD_LAUNCH_CHECK();
     return FCD_OK;

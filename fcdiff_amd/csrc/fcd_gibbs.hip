@@ -418,8 +418,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
 // f step, pair form for ANY number of patients (what cfg5's U = 250 runs).  Same records, same term (one
 // ds_read_b128 + two fp64 adds per PAIR of patients), but
 //   * the tile holds EC edges with EC chosen by the host so that two workgroups share a CU (EC * NPAIR * 256 B <= 80 KiB),
-//   * the pair records are built straight from global memory (no single rows in LDS: at U = 250 they would cost
-//     12 KB per edge), four (edge, pair) records per thread in flight,
+//   * the pair records are built from 384-byte pieces of the rows that each wave stages in a small LDS scratch of its
+//     own (no whole single rows in LDS: at U = 250 they would cost 12 KB per edge), every table byte loaded once,
 //   * the slot words of a group of 16 patients are loaded per group, one group ahead (a wave cannot hold the
 //     16 words per region that U = 250 needs), the group loop is a run-time loop.
 // One Philox block still serves four edges; a tile of EC < 4 edges recomputes it (c0 is a multiple of EC, EC | 4).
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                                                                 const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
                                                                 int GW, uint32_t chain0, uint64_t seed, uint32_t sweep,
                                                                 float margin, uint8_t *__restrict__ fsq) {
-    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [EC][NPAIR][16][2]
+    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [EC][NPAIR][16][2] | staging scratch [waves][2][24][2]
     const int NPAIR = (U + 1) >> 1, NW16 = (U + 15) >> 4;
     const int64_t c0 = (int64_t)blockIdx.x * EC;
     const int ne = (int)((C - c0 < EC) ? (C - c0) : EC);
@@ -443,44 +443,53 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
     // slot words of the first group of the first edge: requested before the build so that their latency hides behind it
     uint32_t rn_c = ru[(uint32_t)((wn * NW16) * 64) + ul], rm_c = ru[(uint32_t)((wm * NW16) * 64) + ul];
     {
-        // pair records straight from the tile's rows of lMf (one contiguous piece of ne * U * 48 bytes): a thread keeps
-        // its slot (blockDim is a multiple of 16) and makes four records per turn, their eight 16-byte loads in flight
-        // together.  A record index beyond the tile is clamped for the loads and dropped at the store.
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        // Pair records from the tile's rows of lMf, every byte of the table loaded ONCE: a wave takes a group of four
+        // pairs of one edge (8 patients = 384 contiguous bytes, fewer at the end of a row; missing patients read as
+        // zero records), lanes 0..23 load one 16-byte value each into the wave's own LDS scratch, then every lane makes
+        // the record entry of its (pair, slot) from two scratch values.  Two groups per turn, their loads in flight together.
+        // (The 16 lanes of a pair loading their two operands straight from memory cost 2.9x the table's bytes in L2
+        // misses at cfg5: the same line requested by several instructions in flight.)
+        const int wv = (int)(threadIdx.x >> 6);
+        double2 *scratch = reinterpret_cast<double2 *>(ptile) + (size_t)EC * NPAIR * 16 + wv * (2 * 24);
         double2 *dst = reinterpret_cast<double2 *>(ptile);
-        const int slot = threadIdx.x & 15;
+        const int slot = lane & 15, pl = lane >> 4;
         const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
         const bool valid = !((x0 & a0) | (x1 & a1));
         const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
-        const int total = ne * NPAIR, stride = blockDim.x >> 4;
-        constexpr int BU = 4;
-        for (int ep0 = threadIdx.x >> 4; ep0 < total; ep0 += BU * stride) {
-            double2 va[BU], vb[BU];
-            bool two[BU];
+        const int NG4 = (NPAIR + 3) >> 2;
+        const int groups = ne * NG4, nwv = (int)(blockDim.x >> 6);
+        const int row_d2 = U * 3;                                                   // 16-byte values per edge row
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
+        for (int g0 = wv; g0 < groups; g0 += 2 * nwv) {
+            double2 v[2];
+            int eq[2][2];
 #pragma unroll
-            for (int j = 0; j < BU; ++j) {
-                const int ep = ep0 + j * stride;
-                const int epc = ep < total ? ep : total - 1;
-                const int e = epc / NPAIR, pr = epc - e * NPAIR;
-                const int u = 2 * pr;
-                const double2 *su = src + (e * U + u) * 3;
-                two[j] = u + 1 < U;
-                va[j] = su[l0];
-                vb[j] = su[two[j] ? 3 + l1 : l0];
+            for (int t = 0; t < 2; ++t) {
+                const int g = g0 + t * nwv;
+                const int gc = g < groups ? g : groups - 1;
+                const int e = gc / NG4, q = gc - e * NG4;
+                eq[t][0] = e;
+                eq[t][1] = q;
+                const int i2 = q * 24 + lane;                                       // value index inside the row
+                v[t] = (lane < 24 && i2 < row_d2) ? src[e * row_d2 + i2] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int j = 0; j < BU; ++j) {
-                const int ep = ep0 + j * stride;
-                double2 v = make_double2(0.0, 0.0);
-                if (valid) {
-                    v = va[j];
-                    if (two[j]) {
-                        v.x += vb[j].x;
-                        v.y += vb[j].y;
-                    }
-                }
-                if (ep < total) dst[ep * 16 + slot] = v;
+            for (int t = 0; t < 2; ++t)
+                if (lane < 24) scratch[t * 24 + lane] = v[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int g = g0 + t * nwv;
+                const int pr = eq[t][1] * 4 + pl;
+                const double2 va = scratch[t * 24 + pl * 6 + l0], vb = scratch[t * 24 + pl * 6 + 3 + l1];
+                const double2 r = valid ? make_double2(va.x + vb.x, va.y + vb.y) : make_double2(0.0, 0.0);
+                if (g < groups && pr < NPAIR) dst[(eq[t][0] * NPAIR + pr) * 16 + slot] = r;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                        // the scratch is free for the next turn
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
     __syncthreads();
@@ -690,6 +699,7 @@ struct tally_args {
     uint32_t *cnt_f, *cnt_r;           // nullable (both or neither)
     double *hyper;                     // nullable: M-step target
     uint32_t *r_U;                     // nullable: slot words of the next f pass
+    int n_f_blocks;                    // blocks that read the state; the rest make r_U
 };
 
 __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
@@ -707,7 +717,11 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
     // Four edges per round, their loads issued together: the pass is a few memory round trips long, what counts is
     // the number of bytes in flight (one 16-byte load per lane and round left the memory side at ~1.4 TB/s).
     constexpr int TE = 4;
-    for (int64_t c0 = ((int64_t)blockIdx.x * 16 + wave) * TE; c0 < C; c0 += (int64_t)gridDim.x * 16 * TE) {
+    // blocks [0, nfb): the f state and the r bits; blocks [nfb, gridDim): the slot words of the next f pass (they run
+    // beside the others on CUs of their own instead of after them)
+    const int nfb = a.n_f_blocks;
+    const bool f_role = (int)blockIdx.x < nfb;
+    for (int64_t c0 = f_role ? ((int64_t)blockIdx.x * 16 + wave) * TE : C; c0 < C; c0 += (int64_t)nfb * 16 * TE) {
         for (int wg = 0; wg < GW; wg += 16) {
             const int w = wg + wrow;
             uint4 vv[TE];
@@ -751,17 +765,17 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
         }
     }
     unsigned long long cr = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NU; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = f_role ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : NU; i < NU; i += (int64_t)nfb * blockDim.x) {
         uint32_t sr = 0;
         for (int w = 0; w < GW; ++w) sr += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
         if (cnt_r) atomicAdd(&cnt_r[i], sr);
         cr += sr;
     }
-    if (a.r_U) {
+    if (a.r_U && !f_role) {
         // slot words of the next f pass: one wave per (w, n, word) item, as pack_ru_kernel
         const int U = a.U, NW16 = a.NW16;
         const int items = GW * a.Nreg * NW16;
-        for (int item = (int)blockIdx.x * 16 + wave; item < items; item += (int)gridDim.x * 16) {
+        for (int item = ((int)blockIdx.x - nfb) * 16 + wave; item < items; item += ((int)gridDim.x - nfb) * 16) {
             const int jw = item % NW16, wn = item / NW16;               // wn = w*Nreg + n
             uint32_t v = 0;
 #pragma unroll
@@ -786,14 +800,17 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
     if (threadIdx.x < 4) {
         unsigned long long t = 0;
         for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
-        if (t) atomicAdd(&a.acc[threadIdx.x], t);
-        __threadfence();                                 // the adds are done before this block's ticket is drawn
+        if (t) {
+            // with the old value asked for, the add has been performed at the memory side once it returns: the
+            // barrier below then orders it before this block's ticket (every access to acc[] is a device-scope atomic)
+            const unsigned long long old = atomicAdd(&a.acc[threadIdx.x], t);
+            asm volatile("" ::"v"(old));
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) sh_last = (atomicAdd(&a.acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
     __syncthreads();
     if (sh_last && threadIdx.x == 0) {
-        __threadfence();
         unsigned long long c5[5];
         for (int i = 0; i < 4; ++i) c5[i] = atomicExch(&a.acc[i], 0ull);     // read at the memory side and reset
         atomicExch(&a.acc[4], 0ull);
@@ -990,13 +1007,13 @@ static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int
         return p;
     }
     const size_t per_edge = (size_t)((U + 1) / 2) * 256;
-    if (f_form != F_DIFF && words_ok && per_edge <= 160 * 1024) {
+    if (f_form != F_DIFF && words_ok && per_edge + 16 * 48 * 16 <= 160 * 1024) {
         // largest tile that still lets two workgroups share a CU; one edge per tile may take the whole LDS
         int ec = 8;
-        while (ec > 1 && (size_t)ec * per_edge > 80 * 1024) ec >>= 1;
+        while (ec > 1 && (size_t)ec * per_edge + 16 * 48 * 16 > 80 * 1024) ec >>= 1;
         p.form = F_PAIRX;
         p.EC = ec;
-        p.shmem = (size_t)ec * per_edge;
+        p.shmem = (size_t)ec * per_edge + 16 * 48 * 16;      // + a 768-byte staging scratch per wave
         return p;
     }
     p.form = F_DIFF;
@@ -1174,6 +1191,12 @@ static int launch_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_
     int64_t blocks = (g.C + 63) / 64;          // 16 waves x 4 edges per workgroup and round
     const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
     if (blocks > cap) blocks = cap;
+    a.n_f_blocks = (int)blocks;
+    if (r_U) {
+        int64_t ru_blocks = ((int64_t)g.GW * Nreg * a.NW16 + 15) / 16;
+        if (ru_blocks > ctx->num_cu) ru_blocks = ctx->num_cu;
+        blocks += ru_blocks;
+    }
     hipLaunchKernelGGL(gibbs_tally_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, a);
     FCD_LAUNCH_CHECK();
     return FCD_OK;

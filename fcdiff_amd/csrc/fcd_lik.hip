@@ -7,6 +7,7 @@
 // The (C,H,3) table of the reference is never consumed except through its H-sum (fit.py:171, :472),
 // so only S_B[c,k] = sum_h lp_B_g_F[c,h,k] is produced unless the caller asks for the full table.
 #include "fcd_common.h"
+#include "fcd_fastmath.h"
 
 namespace {
 
@@ -18,6 +19,7 @@ struct LikTheta {
     double lnsigma[3];
     double eps[3];       // _eval_M_eps(eta, epsilon, l), l = 0,1,2
     double omeps_half[3];  // (1 - eps_l) * 0.5, the reference's evaluation order
+    double cmin;           // min over l of min(eps_l, omeps_half_l): every M_kl >= cmin * (N_0 + N_1 + N_2)
 };
 
 constexpr double kSqrt2Pi = 2.5066282746310002;      // numpy: sqrt(2*pi)
@@ -26,67 +28,32 @@ constexpr double kLogSqrt2Pi = 0.9189385332046727;   // numpy: log(sqrt(2*pi))
 constexpr int LIK_BLOCK = 256;
 
 // ---------------------------------------------------------------------------------------------
-// log for this kernel.  9 of the ~12 transcendental calls per (edge, patient) item are logs and the kernel
-// is ALU-bound on them (the ocml log is ~70 fp64 instructions), so a table-driven one (Tang 1990 style):
-//   x = 2^e * m, m in [0.75, 1.5);  i = top 6 mantissa bits;  r = fma(m, 1/m_i, -1), |r| <= 2^-6;
-//   log x = e*ln2 + log(m_i) + log1p(r),   log1p(r) by a degree-10 Taylor polynomial.
-// m_i = 1 for the two cells around 1, so there is no cancellation for x near 1.  Error <= ~1.5 ulp over the
-// whole positive range (subnormals included); log(0) = -inf as the reference's np.log gives for an
-// underflowed mixture density (fit.py:115, 121-122).  The 64-entry table {1/m_i, log m_i} lives in LDS.
+// exp and log of this kernel: fcd_fastmath.h.  3 of the ~12 transcendental calls per (edge, patient) item are
+// exponentials of -z*z/2 <= 0 and 9 are logarithms of mixture densities; with ocml's exp and log (~35 and ~70 fp64
+// instructions) the kernel is ALU-bound far below the memory system.  fcd_exp_neg (64-entry table of 2^(-j/64) + a
+// degree-6 polynomial, <= 1.0 ulp) and fcd_log_normal (512-entry table {1/m_i, log m_i} + a degree-7 polynomial, <= 1.3
+// ulp, no special cases) take ~18 and ~22.  The logs' special cases are decided ONCE per item: all nine M_kl are
+// >= cmin * (N_0 + N_1 + N_2), so one comparison shows them positive, finite and normal; the rare item at the edge of
+// the double range goes through ocml's log, which gives -inf for an underflowed mixture density exactly like the
+// reference's np.log (fit.py:115, 121-122).  Both tables live in LDS.
 // ---------------------------------------------------------------------------------------------
-struct LogTab {
-    double inv[64];
-    double lg[64];
+struct LikTabs {
+    double exp_tab[FCD_EXP_CELLS];
+    fcd_log_cell log_tab[FCD_LOG_CELLS];
 };
-
-__device__ inline double fast_log(double x, const double2 *__restrict__ tab) {
-    if (!(x > 0.0)) return (x == 0.0) ? -__builtin_inf() : __builtin_nan("");
-    int eadj = 0;
-    if (x < 2.2250738585072014e-308) {   // subnormal: scale by 2^54
-        x *= 18014398509481984.0;
-        eadj = -54;
-    }
-    if (x == __builtin_inf()) return x;
-    const uint64_t bits = (uint64_t)__double_as_longlong(x);
-    const int idx = (int)((bits >> 46) & 63);            // top 6 mantissa bits
-    int e = (int)((bits >> 52) & 0x7FF) - 1023 + eadj;
-    // mantissa in [1, 2); cells 32..63 (m >= 1.5) are halved into [0.75, 1) and the exponent bumped
-    uint64_t mb = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
-    if (idx >= 32) {
-        mb -= 0x0010000000000000ull;
-        e += 1;
-    }
-    const double m = __longlong_as_double((long long)mb);
-    const double2 t = tab[idx];
-    const double r = fma(m, t.x, -1.0);
-    // log1p(r) = r - r^2/2 + r^3/3 - ... - r^10/10
-    double p = -0.1;
-    p = fma(p, r, 1.0 / 9.0);
-    p = fma(p, r, -0.125);
-    p = fma(p, r, 1.0 / 7.0);
-    p = fma(p, r, -1.0 / 6.0);
-    p = fma(p, r, 0.2);
-    p = fma(p, r, -0.25);
-    p = fma(p, r, 1.0 / 3.0);
-    p = fma(p, r, -0.5);
-    const double r2 = r * r;
-    const double de = (double)e;
-    const double hi = fma(de, 6.93147180369123816490e-01, t.y);        // e*ln2_hi + log m_i (ln2_hi has 32 trailing zero bits)
-    const double lo = fma(de, 1.90821492927058770002e-10, fma(p, r2, r));   // e*ln2_lo + log1p(r)
-    return hi + lo;
-}
 
 // One launch, two kinds of blocks.
 // Blocks [0, n_bt_blocks): one thread per (c,u) item; the block's 256 x 9 results are transposed through LDS so that
 //   the 72-byte records leave as fully coalesced 16-byte-per-lane stores (grid-stride over tiles of 256 items).
 // Blocks [n_bt_blocks, ...): 16 lanes per edge, S_B[c,k] = sum_h ( -z*z/2 - log(sqrt(2 pi)) - log(sigma_k) )  (fit.py:114, :171)
 __global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict__ bt, int64_t n_items, LikTheta th,
-                                                        const LogTab *__restrict__ logtab, double *__restrict__ lM,
+                                                        const LikTabs *__restrict__ tabs, double *__restrict__ lM,
                                                         double *__restrict__ pBt, int n_bt_blocks,
                                                         const double *__restrict__ b, int64_t C, int H,
                                                         double *__restrict__ S_B, double *__restrict__ lpB) {
     __shared__ double stage[LIK_BLOCK * 9];
-    __shared__ double2 tab[64];
+    __shared__ __attribute__((aligned(16))) fcd_log_cell ltab[FCD_LOG_CELLS];
+    __shared__ double etab[FCD_EXP_CELLS];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= n_bt_blocks) {
         const int sub = tid & 15;
@@ -122,7 +89,8 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict
         }
         return;
     }
-    if (tid < 64) tab[tid] = make_double2(logtab->inv[tid], logtab->lg[tid]);
+    for (int t = tid; t < FCD_LOG_CELLS; t += LIK_BLOCK) ltab[t] = tabs->log_tab[t];
+    if (tid < FCD_EXP_CELLS) etab[tid] = tabs->exp_tab[tid];
     __syncthreads();
     const int64_t n_tiles = (n_items + LIK_BLOCK - 1) / LIK_BLOCK;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += n_bt_blocks) {
@@ -138,7 +106,7 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict
                 // host-side reciprocals (<= 2 ulp of the density, ~1e-16 relative in log M) ...
                 const double d = x - th.mu[k];
                 const double z = d * th.inv_sigma[k];
-                N[k] = exp(-(z * z) / 2.0) * th.pdf_scale[k];
+                N[k] = fcd_exp_neg((z * z) / 2.0, etab) * th.pdf_scale[k];
                 // ... except at the edge of the double range, where the reference's own roundings decide whether the
                 // density is 0 (lM = -inf) or a subnormal: there its operations are redone exactly (rare branch)
                 if (N[k] < 1e-290) {
@@ -153,12 +121,26 @@ __global__ __launch_bounds__(LIK_BLOCK) void lik_kernel(const double *__restrict
             }
             // js = the two other components in ascending order (fit.py:428-429)
             const double others[3] = {N[1] + N[2], N[0] + N[2], N[0] + N[1]};
+            const double floor_M = th.cmin * (N[0] + others[0]);
+            if (floor_M >= 4.5e-308 && floor_M < __builtin_inf()) {
+                // every M_kl is positive, finite and normal: the branch-free log
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < 3; ++k) {
 #pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    const double M = th.eps[l] * N[k] + th.omeps_half[l] * others[k];  // fit.py:430
-                    stage[tid * 9 + k * 3 + l] = fast_log(M, tab);                     // fit.py:122
+                    for (int l = 0; l < 3; ++l) {
+                        const double M = th.eps[l] * N[k] + th.omeps_half[l] * others[k];  // fit.py:430
+                        stage[tid * 9 + k * 3 + l] = fcd_log_normal(M, ltab);              // fit.py:122
+                    }
+                }
+            } else {
+                // edge of the double range (or eps in {0, 1}): the general log, -inf for an underflowed density
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const double M = th.eps[l] * N[k] + th.omeps_half[l] * others[k];
+                        stage[tid * 9 + k * 3 + l] = log(M);
+                    }
                 }
             }
         }
@@ -201,6 +183,12 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     e2 += (1 - eta) * (1 - epsilon);
     th.eps[2] = e2;
     for (int l = 0; l < 3; ++l) th.omeps_half[l] = (1 - th.eps[l]) * 0.5;
+    th.cmin = th.eps[0];
+    for (int l = 0; l < 3; ++l) {
+        if (!(th.eps[l] >= th.cmin)) th.cmin = th.eps[l];
+        if (!(th.omeps_half[l] >= th.cmin)) th.cmin = th.omeps_half[l];
+    }
+    if (!(th.cmin > 0.0)) th.cmin = 0.0;          // eps outside (0, 1): no floor, every item takes the general log
 
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_items = C * U;
@@ -211,7 +199,7 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     const int64_t n_b_blocks = (C + 15) / 16;
     fcd_prof_begin(ctx, FCD_PROF_LIK, s);
     hipLaunchKernelGGL(lik_kernel, dim3((unsigned)(grid + n_b_blocks)), dim3(LIK_BLOCK), 0, s, bt, n_items, th,
-                       reinterpret_cast<const LogTab *>(ctx->log_tab), lM, p_Bt_g_Ft, (int)grid, b, C, (int)H, S_B, lp_B_g_F);
+                       reinterpret_cast<const LikTabs *>(ctx->log_tab), lM, p_Bt_g_Ft, (int)grid, b, C, (int)H, S_B, lp_B_g_F);
     fcd_prof_end(ctx, FCD_PROF_LIK, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
