@@ -23,6 +23,7 @@ struct fcd_knobs {
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
+    int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
 };
 
@@ -40,6 +41,8 @@ struct fcd_ctx {
     size_t lds_attr[FCD_KA_N];     // largest dynamic-LDS size already set per kernel
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
+    void *side_stream; // hipStream_t + two events for the two-stream r pass (knob r_streams), made by fcd_ctx_create
+    void *ev_fork, *ev_join;
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
     size_t fsq_bytes;

@@ -50,7 +50,7 @@ constexpr int CB = 64, CK = 16, CLD = 18;
 __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict__ ts, const double *__restrict__ mean,
                                                         const double *__restrict__ sdev, int Nreg, int T, int64_t S,
                                                         int fisher_z, double *__restrict__ out) {
-    __shared__ double pa[2][CB * CLD], pb[2][CB * CLD];
+    __shared__ __attribute__((aligned(16))) double pa[2][CB * CLD], pb[2][CB * CLD];
     // block index -> (I, J), I >= J, lower-triangular row-major like the edges themselves
     const int t = blockIdx.x;
     int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -61,29 +61,51 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict
     const int64_t s = blockIdx.y;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    // staging: thread -> (row of the panel, quarter of the 16 k): 4 doubles per panel and step
-    const int prow = tid >> 2, pq = tid & 3;
-    const int ga = I * CB + prow, gb = J * CB + prow;
-    const bool va = ga < Nreg, vb = gb < Nreg && !diag;
-    const double *xa = ts + (s * Nreg + (va ? ga : 0)) * T;
-    const double *xb = ts + (s * Nreg + (vb ? gb : 0)) * T;
-    const double ma = va ? mean[s * Nreg + ga] : 0.0, mb = vb ? mean[s * Nreg + gb] : 0.0;
-    double ra[4], rb[4];
-    auto fetch = [&](int k0) {
+    // staging: thread -> (row r of the panel, 16-byte piece p of its 128 bytes), rows r and r + 32: eight lanes cover one
+    // whole 128-byte line per load instruction (T even: rows are 16-byte aligned; odd T takes the 8-byte path)
+    const int prow = tid >> 3, pp = tid & 7;
+    const bool even = (T & 1) == 0;
+    int ga[2], gb[2];
+    bool va[2], vb[2];
+    const double *xa[2], *xb[2];
+    double ma[2], mb[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + pq * 4 + q;
-            const int kc = k < T ? k : T - 1;                  // clamped: no branch around the load
-            const double a = xa[kc], b = xb[kc];
-            ra[q] = (va && k < T) ? a - ma : 0.0;
-            rb[q] = (vb && k < T) ? b - mb : 0.0;
+    for (int h = 0; h < 2; ++h) {
+        ga[h] = I * CB + prow + 32 * h;
+        gb[h] = J * CB + prow + 32 * h;
+        va[h] = ga[h] < Nreg;
+        vb[h] = gb[h] < Nreg && !diag;
+        xa[h] = ts + (s * Nreg + (va[h] ? ga[h] : 0)) * T;
+        xb[h] = ts + (s * Nreg + (vb[h] ? gb[h] : 0)) * T;
+        ma[h] = va[h] ? mean[s * Nreg + ga[h]] : 0.0;
+        mb[h] = vb[h] ? mean[s * Nreg + gb[h]] : 0.0;
+    }
+    double2 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+        const int k = k0 + 2 * pp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double2 a, b;
+            if (even) {
+                const int kc = k < T ? k : T - 2;              // clamped: no branch around the load
+                a = *reinterpret_cast<const double2 *>(xa[h] + kc);
+                b = *reinterpret_cast<const double2 *>(xb[h] + kc);
+            } else {
+                const int k0c = k < T ? k : T - 1, k1c = k + 1 < T ? k + 1 : T - 1;
+                a = make_double2(xa[h][k0c], xa[h][k1c]);
+                b = make_double2(xb[h][k0c], xb[h][k1c]);
+            }
+            ra[h].x = (va[h] && k < T) ? a.x - ma[h] : 0.0;
+            ra[h].y = (va[h] && k + 1 < T) ? a.y - ma[h] : 0.0;
+            rb[h].x = (vb[h] && k < T) ? b.x - mb[h] : 0.0;
+            rb[h].y = (vb[h] && k + 1 < T) ? b.y - mb[h] : 0.0;
         }
     };
     auto put = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            pa[buf][prow * CLD + pq * 4 + q] = ra[q];
-            if (!diag) pb[buf][prow * CLD + pq * 4 + q] = rb[q];
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<double2 *>(&pa[buf][(prow + 32 * h) * CLD + 2 * pp]) = ra[h];
+            if (!diag) *reinterpret_cast<double2 *>(&pb[buf][(prow + 32 * h) * CLD + 2 * pp]) = rb[h];
         }
     };
     double4_t acc[2][2];

@@ -471,7 +471,13 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                 eq[t][0] = e;
                 eq[t][1] = q;
                 const int i2 = q * 24 + lane;                                       // value index inside the row
-                v[t] = (lane < 24 && i2 < row_d2) ? src[e * row_d2 + i2] : make_double2(0.0, 0.0);
+                // (read once, by this workgroup only: non-temporal, so the stream does not push the r words out of L2)
+                if (lane < 24 && i2 < row_d2) {
+                    const double *p2 = reinterpret_cast<const double *>(src + (e * row_d2 + i2));
+                    v[t] = make_double2(__builtin_nontemporal_load(p2), __builtin_nontemporal_load(p2 + 1));
+                } else {
+                    v[t] = make_double2(0.0, 0.0);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)

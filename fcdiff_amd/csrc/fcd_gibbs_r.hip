@@ -189,6 +189,8 @@ struct r_step_args {
     double *Pbuf[2];        // e = (dpi + panel sum) - threshold: P(s) writes [s & 1], D(s) reads it
     uint32_t *flags;        // one-launch form: cntP[wg][uc][s] | cntD[wg][uc][s] | error word; else nullptr
     int Nreg, U, NBLK, GW;
+    int u_lo, u_n;          // the patients this launch serves: [u_lo, u_lo + u_n)  (patients are independent given f: a pass
+                            // may run as two half-passes on two streams, see fcd_gibbs_r_step_sq)
     int wpb, nWG;           // chain words per workgroup, groups of chain words
     int s, nD, nP;          // step-per-launch form: the step and the number of workgroups per role
     int ncu, npad;          // ... CUs of the device; empty workgroups at [ncu, ncu + npad) (beside the D workgroups)
@@ -265,8 +267,8 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     double *pairs = smem;                                  // [n_pairs][UB][36]
     double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][16 NBLK regions * 6], zero beyond Nreg
     const int n = st * R_NB + row;
-    const int u0 = uc * UB;
-    const int nu = (U - u0 < UB) ? (U - u0) : UB;
+    const int u0 = a.u_lo + uc * UB;
+    const int nu = (a.u_lo + a.u_n - u0 < UB) ? (a.u_lo + a.u_n - u0) : UB;
     if (FCD_ABL(1, 5)) return true;       // ablation: empty role
     [[maybe_unused]] const int trec = st * 1024 + (int)blockIdx.x;
     FCD_TRACE(trec, 0);
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int blk = blockIdx.x;
     if (blk < a.nD) {
-        r_role_diag<false>(a, a.s - 1, blk % a.U, blk / a.U, smem, nullptr, 0u, nullptr, nullptr);
+        r_role_diag<false>(a, a.s - 1, a.u_lo + blk % a.u_n, blk / a.u_n, smem, nullptr, 0u, nullptr, nullptr);
     } else {
         int item = blk - a.nD;
         if (a.npad) {
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
             }
         }
         const int rows = (a.Nreg - a.s * R_NB < R_NB) ? (a.Nreg - a.s * R_NB) : R_NB;
-        const int nUC = (a.U + UB - 1) / UB;
+        const int nUC = (a.u_n + UB - 1) / UB;
         r_role_panel<UB, false>(a, a.s, item % rows, (item / rows) % nUC, item / (rows * nUC), smem, nullptr, 0u, nullptr, nullptr);
     }
 }
@@ -899,14 +901,14 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
 }
 
 template <int UB, int WPE>
-int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s) {
+int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s, bool prof) {
     {
         int rc = fcd_lds_attr(ctx, FCD_KA_R_STEP + (UB == 4 ? 2 : UB - 1), reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), shmem);
         if (rc) return rc;
     }
-    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
+    if (prof) fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
     hipLaunchKernelGGL((gibbs_r_step_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(64 * a.wpb), shmem, s, a);
-    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
+    if (prof) fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -1088,6 +1090,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
     a.flags = nullptr;
     a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;
+    a.u_lo = 0; a.u_n = (int)U;
     a.wpb = g.GW < 16 ? g.GW : 16;
     a.nWG = (g.GW + a.wpb - 1) / a.wpb;
     a.s = 0; a.nD = 0; a.nP = 0;
@@ -1131,16 +1134,42 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         }
         a.flags = nullptr;
     }
+    // Patients are independent given f, so the pass may run as TWO half-passes (patients [0, U0) and [U0, U)) on two
+    // streams: each half is its own chain of step launches, nothing crosses between them, and the tail of one half's
+    // launch (CUs left with one or no workgroup) fills with the other half's next launch instead of idling until the
+    // boundary.  One fork and one join per pass (knob r_streams = 2; U0 a multiple of 2 ub so that Philox blocks and
+    // panel chunks stay whole).
+    int n_half = 1, U0 = (int)U;
+    if (ctx->knobs.r_streams == 2 && ctx->side_stream && U >= 4 * ub) {
+        n_half = 2;
+        U0 = (int)(U / 2) / (2 * ub) * (2 * ub);
+        if (U0 < 2 * ub) U0 = 2 * ub;
+    }
+    hipStream_t hs[2] = {s, n_half == 2 ? (hipStream_t)ctx->side_stream : s};
+    if (n_half == 2) {
+        FCD_HIP_TRY(hipEventRecord((hipEvent_t)ctx->ev_fork, s));
+        FCD_HIP_TRY(hipStreamWaitEvent(hs[1], (hipEvent_t)ctx->ev_fork, 0));
+    }
     for (int st = 0; st <= NBLK; ++st) {
         const int rows = st < NBLK ? (int)((Nreg - (int64_t)st * R_NB < R_NB) ? (Nreg - (int64_t)st * R_NB) : R_NB) : 0;
-        a.s = st;
-        a.nD = st >= 1 ? (int)U * a.nWG : 0;
-        a.nP = rows * nUC * a.nWG;
-        a.npad = (!ctx->knobs.r_nopad && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
-        if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s);
-        else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s);
-        else rc = launch_step<1, 8>(ctx, a, shmem, s);
-        if (rc) return rc;
+        for (int h = 0; h < n_half; ++h) {
+            a.u_lo = h == 0 ? 0 : U0;
+            a.u_n = n_half == 1 ? (int)U : (h == 0 ? U0 : (int)U - U0);
+            const int nUCh = (a.u_n + ub - 1) / ub;
+            a.s = st;
+            a.nD = st >= 1 ? a.u_n * a.nWG : 0;
+            a.nP = rows * nUCh * a.nWG;
+            a.npad = (!ctx->knobs.r_nopad && n_half == 1 && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+            if (a.nD + a.nP == 0) continue;
+            if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, hs[h], h == 0);
+            else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, hs[h], h == 0);
+            else rc = launch_step<1, 8>(ctx, a, shmem, hs[h], h == 0);
+            if (rc) return rc;
+        }
+    }
+    if (n_half == 2) {
+        FCD_HIP_TRY(hipEventRecord((hipEvent_t)ctx->ev_join, hs[1]));
+        FCD_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)ctx->ev_join, 0));
     }
     return FCD_OK;
 }

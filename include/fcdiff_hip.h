@@ -74,12 +74,13 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 /* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL,
- * FCD_F_FORM, read once by fcd_ctx_create; 0 = default everywhere):
+ * FCD_F_FORM, FCD_R_STREAMS, read once by fcd_ctx_create; 0 = default everywhere):
  *   "r_path"    1: row-sequential single-launch r pass instead of the blocked one (alternative, slower)
  *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
  *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
+ *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
  * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
 int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value);

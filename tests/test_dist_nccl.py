@@ -1,0 +1,82 @@
+"""
+Two ranks on two GPUs over RCCL (torch.distributed backend "nccl"): the HIP GibbsEngine under run_chains, both M-step
+schedules, against the single-process run of the same global chains.  Skips when fewer than two GPUs are visible (the
+build box has one; the driver's 8-GPU node runs it).  Each rank is a fresh child process started BEFORE anything touches
+the GPU (torch.multiprocessing spawn), one process per GPU, rendezvous on 127.0.0.1.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import fcdiff_amd
+        from fcdiff_amd.gibbs import GibbsEngine, run_chains, shard_chains
+        (N, H, U) = (24, 6, 10)
+        m = fcdiff_amd.UnsharedRegionModel()
+        (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=3)
+        fit = fcdiff_amd.fit.UnsharedRegionFit()
+        fit.model, fit.b, fit.bt = m, b, bt
+        fit._init_lps(N, H, U)
+        fit._update_lps()
+        (chain0, n_local) = shard_chains(total, world, rank)
+        eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], N, U, n_local, chain0=chain0, seed=seed, ctx=fit._context())
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.2)
+        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag)
+        torch.cuda.synchronize()
+        (f, r) = eng.export_state()
+        cnt = eng.cnt_r.to(torch.int64).clone()
+        dist.all_reduce(cnt)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=f, r=r, hyper=eng.hyper.cpu().numpy(), chain0=chain0,
+                 cnt_r=cnt.cpu().numpy(), world=dist.get_world_size())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (2, 1)])
+def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag):
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    (total, n_sweeps, seed) = (192, 6, 31)
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    # children only: the parent never initialises the GPU
+    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(one)), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(two)), nprocs=2, join=True)
+    ref = np.load(os.path.join(str(one), "rank0.npz"))
+    parts = [np.load(os.path.join(str(two), "rank%d.npz" % r)) for r in range(2)]
+    assert [int(p["world"]) for p in parts] == [2, 2] and [int(p["chain0"]) for p in parts] == [0, 96]
+    np.testing.assert_array_equal(np.concatenate([p["f"] for p in parts]), ref["f"])
+    np.testing.assert_array_equal(np.concatenate([p["r"] for p in parts]), ref["r"])
+    for p in parts:
+        np.testing.assert_array_equal(p["hyper"], ref["hyper"])       # the same pooled (pi, gamma) on every rank
+        np.testing.assert_array_equal(p["cnt_r"], ref["cnt_r"])

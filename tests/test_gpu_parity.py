@@ -456,6 +456,31 @@ def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     nptest.assert_array_equal(r_g, r_o)
 
 
+@pytest.mark.parametrize("N,U,G,mode,ub", [(40, 9, 128, "symmetric", 0), (33, 21, 1024, "reference", 0), (70, 12, 200, "symmetric", 1),
+                                           (20, 250, 128, "symmetric", 0)])
+def test_gibbs_r_pass_on_two_streams(env, knobs, N, U, G, mode, ub):
+    """
+    Knob r_streams=2: the blocked r pass as two half-passes over the patients (odd and even splits, one- and
+    two-patient panels, U > 64) on two streams gives the oracle's chains, sweep after sweep (the fork / join keeps the
+    f pass, the packing and the tally in order with both halves).
+    """
+    knobs(r_streams=2, r_ub=ub)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    seed = 17 + N
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    eng.run(0, 3, mstep_every=0)
+    for s in range(3):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 64)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,U,G,mode", [(17, 1, 64, "symmetric"), (16, 2, 70, "symmetric"), (32, 3, 2048, "symmetric"),
                                         (250, 4, 64, "symmetric"), (33, 7, 1100, "reference"), (3, 2, 64, "symmetric"),
