@@ -194,8 +194,8 @@ extern "C" int fcd_lik_tables(fcd_ctx *ctx, const double *b, const double *bt, i
     const int64_t n_items = C * U;
     const int64_t n_tiles = (n_items + LIK_BLOCK - 1) / LIK_BLOCK;
     int64_t grid = n_tiles;                          // one tile per block up to 16 blocks per CU, grid-stride beyond
-    const int64_t cap = (int64_t)ctx->num_cu * 16;
-    if (grid > cap) grid = cap;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;   // (5 per CU, all resident, each copying the tables once: the same 26 us
+    if (grid > cap) grid = cap;                      //  at cfg3 and 4 % slower at cfg5 -- queued blocks even out the tail)
     const int64_t n_b_blocks = (C + 15) / 16;
     fcd_prof_begin(ctx, FCD_PROF_LIK, s);
     hipLaunchKernelGGL(lik_kernel, dim3((unsigned)(grid + n_b_blocks)), dim3(LIK_BLOCK), 0, s, bt, n_items, th,

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long
     else a = (s % 3) * 16;
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     const char *b = (const char *)lds;
+    const long long rt0 = (long long)wall_clock64();
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -47,7 +48,11 @@ __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long
     }
     long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = d0 + d1 + d2 + d3;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        cyc[blockIdx.x] = t1 - t0;
+        cyc[256 + blockIdx.x] = rt0;                       // 100 MHz wall clock at the start / end of the loop
+        cyc[512 + blockIdx.x] = (long long)wall_clock64();
+    }
 }
 
 template <int MODE>
@@ -65,6 +70,22 @@ int run(const char *name, int waves_per_block, int *sel, double *out, long long 
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     long long c;
     CHECK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    {
+        // were all blocks in flight together, and what clock did they run at?  (s_memtime = shader cycles, wall_clock64 = 100 MHz)
+        std::vector<long long> h(768);
+        CHECK(hipMemcpy(h.data(), cyc, 768 * 8, hipMemcpyDeviceToHost));
+        long long s0 = h[256], s1 = h[256], e0 = h[512], e1 = h[512];
+        double clk = 0;
+        for (int b = 0; b < blocks; ++b) {
+            if (h[256 + b] < s0) s0 = h[256 + b];
+            if (h[256 + b] > s1) s1 = h[256 + b];
+            if (h[512 + b] < e0) e0 = h[512 + b];
+            if (h[512 + b] > e1) e1 = h[512 + b];
+            clk += (double)h[b] / ((double)(h[512 + b] - h[256 + b]) * 10.0);       // cycles per ns
+        }
+        printf("    blocks start within %.1f us, end within %.1f us of each other; loop %.1f us; mean in-kernel clock %.2f GHz\n",
+               (s1 - s0) / 100.0, (e1 - e0) / 100.0, (e1 - s0) / 100.0, clk / blocks);
+    }
     const double wave_instr = (double)iters * 16 * 4;      // read(+add) groups per wave
     const double ns_per = ms * 1e6 / wave_instr;           // per wave-instruction-group, one wave's timeline
     printf("%-44s waves/CU=%2d  %8.3f ms  %6.2f ns per (read+add) per wave  -> %6.2f ns per SIMD-slot; memtime ticks %lld (%.1f ticks/us)\n",
@@ -76,9 +97,9 @@ int main() {
     int h[64];
     for (int i = 0; i < 64; ++i) h[i] = (i * 7 + i / 5) % 6;
     int *sel; double *out; long long *cyc;
-    CHECK(hipMalloc(&sel, 256)); CHECK(hipMalloc(&out, 256 * 1024 * 8)); CHECK(hipMalloc(&cyc, 256 * 8));
+    CHECK(hipMalloc(&sel, 256)); CHECK(hipMalloc(&out, 256 * 1024 * 8)); CHECK(hipMalloc(&cyc, 768 * 8));
     CHECK(hipMemcpy(sel, h, 256, hipMemcpyHostToDevice));
-    for (int wpb : {4, 16}) {
+    for (int wpb : {4, 8, 16}) {
         run<0>("b64 gather 6 addrs/48B (panel pattern)", wpb, sel, out, cyc);
         run<1>("b64 64 distinct consecutive", wpb, sel, out, cyc);
         run<2>("b64 all lanes same address", wpb, sel, out, cyc);
