@@ -70,6 +70,7 @@ SIGNATURES = {
     "fcd_gibbs_run": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _i64, _i64, _p, _p,
                             _p, _p]),
     "fcd_gibbs_logjoint": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "fcd_gibbs_chain_rsum": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "fcd_gibbs_conditionals": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "fcd_gibbs_export_state": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "fcd_gibbs_import_state": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),

@@ -861,6 +861,18 @@ __global__ __launch_bounds__(64) void gibbs_logjoint_kernel(const double *__rest
     partial[((int64_t)s * GW + w) * 64 + lane] = acc;
 }
 
+// per-chain number of anomalous (region, patient) sites: sum_{n,u} r_nu -- the scalar SURVEY.md section 8f item 4 names
+// for the chain diagnostics next to the log-joint.  One wave per (chain word, slice of the sites); out is zeroed first.
+__global__ __launch_bounds__(64) void gibbs_rsum_kernel(const uint64_t *__restrict__ r_bits, int64_t NU, int64_t G,
+                                                        unsigned int *__restrict__ out) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const uint64_t *rw = r_bits + (int64_t)w * NU;
+    unsigned int ones = 0;
+    for (int64_t i = blockIdx.y; i < NU; i += gridDim.y) ones += (unsigned int)((rw[i] >> lane) & 1ull);
+    const int64_t g = (int64_t)w * 64 + lane;
+    if (g < G && ones) atomicAdd(&out[g], ones);
+}
+
 __global__ void gibbs_logjoint_fold(const double *__restrict__ partial, int64_t GWx64, int64_t G, double *__restrict__ out) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
@@ -1290,6 +1302,21 @@ extern "C" int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double 
     FCD_LAUNCH_CHECK();
     hipLaunchKernelGGL(gibbs_logjoint_fold, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, (const double *)ctx->ws,
                        (int64_t)g.GW * 64, G, out);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_chain_rsum(fcd_ctx *ctx, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, uint32_t *out,
+                                    fcd_stream stream) {
+    fcd_geo g;
+    int rc = fcd_geo_check(ctx, Nreg, U, G, 0, g);
+    if (rc) return rc;
+    if (!r_bits || !out) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_chain_rsum: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    FCD_HIP_TRY(hipMemsetAsync(out, 0, (size_t)G * sizeof(uint32_t), s));
+    const int64_t NU = Nreg * U;
+    const int slices = (int)(NU < 64 ? NU : 64);
+    hipLaunchKernelGGL(gibbs_rsum_kernel, dim3((unsigned)g.GW, (unsigned)slices), dim3(64), 0, s, r_bits, NU, G, out);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

@@ -196,6 +196,7 @@ struct r_step_args {
     int ncu, npad;          // ... CUs of the device; empty workgroups at [ncu, ncu + npad) (beside the D workgroups)
     uint32_t chain0, sweep;
     uint64_t seed;
+    int prefetch;           // panel role: touch the next step's table rows (knob r_prefetch)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
 };
 
@@ -363,6 +364,21 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     }
     __syncthreads();
     FCD_TRACE(trec, 2);
+    if (a.prefetch && st + 1 < NBLK) {
+        // Touch the table rows the SAME workgroup slot of the next launch will stage (region n + 16, the same patients):
+        // launches deal their workgroups to the XCDs in the same order, so the lines wait in this XCD's L2 (a hint only:
+        // nothing depends on it).  One dword per 128-byte line, the value is thrown away.
+        const int nn = n + R_NB;
+        if (nn < Nreg) {
+            const int lines_per_row = (Nreg * 48 + 127) >> 7;
+            for (int it = threadIdx.x; it < UB * lines_per_row; it += blockDim.x) {
+                const int u = it / lines_per_row, ln = it - u * lines_per_row;
+                const int us = u < nu ? u : nu - 1;
+                const char *rowp = reinterpret_cast<const char *>(a.lMd + ((int64_t)(u0 + us) * Nreg + nn) * Nreg * 6);
+                (void)*reinterpret_cast<const volatile uint32_t *>(rowp + (size_t)ln * 128);     // (no use: no wait)
+            }
+        }
+    }
     if (!live) return true;
     // LDS byte offset of the tile: reads go through an LDS-space pointer so that (block base + pair, patient offset)
     // becomes scalar base + instruction immediate
@@ -1096,6 +1112,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.s = 0; a.nD = 0; a.nP = 0;
     a.ncu = ctx->num_cu; a.npad = 0;
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
+    a.prefetch = ctx->knobs.r_prefetch;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);

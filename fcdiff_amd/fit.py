@@ -66,7 +66,8 @@ class UnsharedRegionFit(object):
         self.theta_sub_every = 0   # gibbs: re-fit (eta, epsilon) from pooled chain counts every this many sweeps (0: never)
         self.energy_every = 0
         self.trace_every = 0       # gibbs: keep every chain's log-joint every this many sweeps in `trace` (chains, draws)
-        self.trace = None
+        self.trace = None          # ... and its number of anomalous sites sum_{n,u} r_nu in `trace_r`
+        self.trace_r = None
         self.seed = 0
         self.chain0 = 0
         self.sampler = None       # the GibbsEngine of the last gibbs run
@@ -393,11 +394,17 @@ class UnsharedRegionFit(object):
         self.model.gamma = self._theta_step(lq_R=lq_R, lq_F=lq_F)[1:4].copy()
 
     def diagnostics(self):
-        """split-R-hat / effective sample size of the per-chain log-joint trace of the last gibbs run (trace_every > 0)."""
+        """
+        split-R-hat / effective sample size of the per-chain traces of the last gibbs run (trace_every > 0): the
+        log-joint (the summary's own keys, as before) and, under "sum_r", the number of anomalous sites sum_{n,u} r_nu.
+        """
         from . import diagnostics as D
         if self.trace is None or self.trace.shape[1] < 4:
             raise ValueError("no trace: set trace_every > 0 and keep at least 4 recorded sweeps after burn_in")
-        return D.summary(self.trace)
+        out = D.summary(self.trace)
+        if self.trace_r is not None:
+            out["sum_r"] = D.summary(self.trace_r)
+        return out
 
     def _update_theta_sub(self):
         """
@@ -448,6 +455,7 @@ class UnsharedRegionFit(object):
         self.energy = []
 
         traces = []
+        traces_r = []
 
         def record(i, e):
             want_e = bool(self.energy_every and (i + 1) % self.energy_every == 0)
@@ -458,6 +466,7 @@ class UnsharedRegionFit(object):
                     self.energy.append(-float(lj.mean()))
                 if want_t:
                     traces.append(lj.cpu().numpy())
+                    traces_r.append(e.r_sums().cpu().numpy())
             if self.update_theta_sub and self.theta_sub_every and (i + 1) % self.theta_sub_every == 0 and i + 1 < self.n_sweeps:
                 # Monte-Carlo EM for (eta, epsilon): pooled counts of (f_c, mixture case) over all chains of all ranks
                 W = e.pair_counts()
@@ -476,6 +485,7 @@ class UnsharedRegionFit(object):
                    update_theta=True, on_sweep=record if needs_callback else None, mstep_lag=self.mstep_lag)
         self.sampler = eng
         self.trace = np.stack(traces, axis=1) if traces else None
+        self.trace_r = np.stack(traces_r, axis=1).astype(np.float64) if traces_r else None
         # marginals pooled over this rank's chains and, when distributed, over all ranks
         cnt = t.cat([eng.cnt_f.reshape(-1).to(t.int64), eng.cnt_r.reshape(-1).to(t.int64),
                      t.tensor([eng.n_accumulated * eng.G], dtype=t.int64, device=eng.cnt_f.device)])

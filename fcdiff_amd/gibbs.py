@@ -200,6 +200,13 @@ class GibbsEngine(object):
                       _lib.stream_ptr())
         return out
 
+    def r_sums(self):
+        """(G,) int32: number of anomalous (region, patient) sites of each chain (fcd_gibbs_chain_rsum)."""
+        out = self.torch.empty(self.G, dtype=self.torch.int32, device=self.f_state.device)
+        self.ctx.call("fcd_gibbs_chain_rsum", _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, _lib.dptr(out),
+                      _lib.stream_ptr())
+        return out
+
     def conditionals(self, want_f=True, want_r=True):
         t = self.torch
         dev = self.f_state.device

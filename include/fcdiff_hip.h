@@ -248,6 +248,10 @@ int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const doubl
 int fcd_gibbs_logjoint(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,
                        const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                        double *out, fcd_stream stream);
+/* Number of anomalous (region, patient) sites of each chain, sum_{n,u} r_nu: out (G,) uint32 (overwritten).  The second
+ * scalar of the chain diagnostics (split R-hat / ESS), next to the log-joint. */
+int fcd_gibbs_chain_rsum(fcd_ctx *ctx, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, uint32_t *out,
+                         fcd_stream stream);
 /* Unnormalised conditional log-weights of EVERY site given the current state, nothing updated:
  * cond_f (G, C, 3), cond_r (G, Nreg, U, 2).  Either may be NULL.  (Parity hook + Rao-Blackwell use.) */
 int fcd_gibbs_conditionals(fcd_ctx *ctx, const double *S_B, const double *lM, const double *hyper,

@@ -641,6 +641,11 @@ def test_fit_gibbs_recovers_planted_structure(env):
     fit.run()
     d = fit.diagnostics()                     # per-chain log-joint trace: 128 chains x 15 recorded sweeps
     assert fit.trace.shape == (128, 15) and d["chains"] == 128 and np.isfinite(d["rhat"]) and d["ess"] > 10
+    # ... and the number of anomalous sites per chain (the other scalar of SURVEY 8f item 4), equal to a recount
+    assert fit.trace_r.shape == (128, 15) and d["sum_r"]["chains"] == 128 and np.isfinite(d["sum_r"]["rhat"])
+    (_f_last, r_last) = fit.sampler.export_state()
+    nptest.assert_array_equal(fit.sampler.r_sums().cpu().numpy(), r_last.reshape(128, -1).sum(axis=1))
+    nptest.assert_array_equal(fit.trace_r[:, -1], r_last.reshape(128, -1).sum(axis=1))
     assert fit._lq_F.shape == (N * (N - 1) // 2, 1, 3) and fit._lq_R.shape == (N, U, 2)
     assert (np.argmax(fit._lq_F[:, 0, :], axis=1) == np.argmax(f, axis=1)).mean() > 0.98
     assert ((np.exp(fit._lq_R[:, :, 1]) > 0.5) == r).mean() > 0.9
