@@ -23,6 +23,7 @@ struct fcd_knobs {
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
+    int r_nopre;       // 1: ignore the pair-record table (build the records in LDS at every block step)
     int r_prefetch;    // 1: panel workgroups touch the table rows of the next block step (L2 warm-up hint)
     int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
@@ -95,9 +96,9 @@ static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t sh
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready);
-int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper, const uint8_t *f_state,
-                        uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep,
-                        int edge_mode, hipStream_t stream, const uint8_t *fsq);
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+                        const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq);
 // bracket ONE kernel launch with events when profiling is on (no-ops otherwise)
 void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s);
 void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s);

@@ -1136,7 +1136,7 @@ extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint6
 }
 
 extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                                const double *hyper,
+                                const double *lMp, const double *hyper,
                                 uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                                 uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                                 fcd_stream stream) {
@@ -1161,7 +1161,7 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
         int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,
                                      (hipStream_t)stream, fsq, false);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
                                  (hipStream_t)stream, fsq);
         if (rc) return rc;
     }
@@ -1235,7 +1235,7 @@ extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint6
 // run_chains and bench.py call).  Per sweep: f pass (1 launch), packing for the r pass (1), block steps of the r pass
 // (ceil(Nreg/16) + 1), tally (1) -- the tally also carries the M-step and the slot words of the next f pass.
 extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                             double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                             const double *lMp, double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                              int64_t chain0, uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode,
                              int64_t mstep_every, int64_t accumulate_from, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r,
                              fcd_stream stream) {
@@ -1268,7 +1268,7 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
     for (int64_t i = 0; i < n_sweeps; ++i) {
         rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
         if (rc) return rc;
         const bool last = i + 1 == n_sweeps;
         const bool do_m = mstep_every > 0 && (i + 1) % mstep_every == 0;

@@ -58,6 +58,33 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// region-major PAIR-RECORD table (optional, made once per table build from lMd): lMp (U, Nreg, NP, 9, 4), NP = 8 ceil(Nreg/16),
+//   lMp[u][n][p][q = 3k + k'][tt = t + 2t'] = lMd[u][n][2p][k][t] + lMd[u][n][2p+1][k'][t']      (zero records beyond Nreg)
+// i.e. exactly the records the panel and in-order roles otherwise build in LDS at every block step (same additions,
+// same bits).  With it a workgroup copies its tile straight into LDS: no single rows, no build phase, one barrier
+// less -- at the price of streaming 288 B instead of 96 B per pair of regions from memory.  One thread per (record, q).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void region_pair_tables_kernel(const double *__restrict__ lMd, int Nreg, int U, int NP,
+                                                                 double *__restrict__ lMp) {
+    const int64_t total = (int64_t)U * Nreg * NP * 9;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(it % 9);
+        const int64_t rec = it / 9;
+        const int p = (int)(rec % NP);
+        const int64_t un = rec / NP;                      // u * Nreg + n
+        const int k = q / 3, k2 = q - 3 * k;
+        const int m0 = 2 * p, m1 = m0 + 1;
+        const double *row = lMd + un * Nreg * 6;
+        double2 a2 = make_double2(0.0, 0.0), b2 = a2;
+        if (m0 < Nreg) a2 = *reinterpret_cast<const double2 *>(row + m0 * 6 + 2 * k);
+        if (m1 < Nreg) b2 = *reinterpret_cast<const double2 *>(row + m1 * 6 + 2 * k2);
+        double2 *dst = reinterpret_cast<double2 *>(lMp + rec * 36 + q * 4);
+        dst[0] = make_double2(a2.x + b2.x, a2.y + b2.x);
+        dst[1] = make_double2(a2.x + b2.y, a2.y + b2.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-pass packing of the chain state into the forms the blocked kernels read with one coalesced load per 16
 // regions (= 8 PAIRS of regions (2p, 2p+1)).  A pair record in LDS is [q = 3 f(n,m) + f(n,m+1)][tt = r_m + 2 r_m+1]
 // doubles, so the byte offset of a term is (q << 5) | (tt << 3) = ((q << 2) | tt) << 3: the words carry ONE BYTE per
@@ -180,6 +207,7 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
 // ---------------------------------------------------------------------------------------------
 struct r_step_args {
     const double *lMd, *hyper;
+    const double *lMp;      // pair-record table (nullable): tiles are copied from it instead of being built in LDS
     const uint2 *f_S;       // f pair bytes (q << 2)
     const uint16_t *r_T;    // r words before the pass (pack_r): what the blocks above the current one still hold
     uint16_t *r_Tn;         // r words redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
@@ -275,7 +303,41 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 1);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
-    {
+    const bool pre = a.lMp != nullptr;
+    if (pre) {
+        // the tile from the pair-record table: record (pair, patient) = 18 pieces of 16 bytes, read once by this
+        // workgroup only (non-temporal), four or so pieces per thread in flight
+        const int n_d2 = n_pairs * UB * 18;
+        double2 *dst = reinterpret_cast<double2 *>(pairs);
+        const double *rowp[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int us = u < nu ? u : nu - 1;                        // tail chunk: replicate the last patient (never stored)
+            rowp[u] = a.lMp + ((int64_t)(u0 + us) * Nreg + n) * n_pairs * 36;
+        }
+        constexpr int SU = 4;
+        for (int it0 = threadIdx.x; it0 < n_d2; it0 += SU * blockDim.x) {
+            double2 v[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                const int itc = it < n_d2 ? it : n_d2 - 1;             // clamped: no branch around the load
+                const int recl = itc / 18, c = itc - recl * 18;        // LDS record (pair * UB + u), piece
+                const int pr = recl / UB, u = recl - pr * UB;
+                const double *src = rowp[0];
+#pragma unroll
+                for (int uu = 1; uu < UB; ++uu)
+                    if (u == uu) src = rowp[uu];
+                src += pr * 36 + c * 2;
+                v[j] = make_double2(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                if (it < n_d2) dst[it] = v[j];
+            }
+        }
+    } else {
         // rows padded with zero records to a whole number of blocks: the pair build below needs no guards
         const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3;
         double2 *dst = reinterpret_cast<double2 *>(single);
@@ -344,7 +406,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     __syncthreads();
     FCD_TRACE(trec, 1);
     if (FCD_ABL(1, 4)) return true;       // ablation: single rows staged, no pair records
-    {
+    if (!pre) {
         // pair records: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries from two 16-byte
         // reads -- [k][t = 0, 1] of region m and [k'][t' = 0, 1] of region m+1 -- and two 16-byte writes: a third of the
         // LDS instructions of one entry per thread, and two turns through the (pair, patient) list instead of seven
@@ -361,10 +423,10 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
                 dst[1] = make_double2(a2.x + b2.y, a2.y + b2.y);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     FCD_TRACE(trec, 2);
-    if (a.prefetch && st + 1 < NBLK) {
+    if (a.prefetch && st + 1 < NBLK && !pre) {
         // Touch the table rows the SAME workgroup slot of the next launch will stage (region n + 16, the same patients):
         // launches deal their workgroups to the XCDs in the same order, so the lines wait in this XCD's L2 (a hint only:
         // nothing depends on it).  One dword per 128-byte line, the value is thrown away.
@@ -461,7 +523,34 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 2);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
-    {
+    const bool pre = a.lMp != nullptr;
+    if (pre) {
+        // both tiles from the pair-record table: row i of the block = 8 records (2 304 contiguous bytes) per tile
+        const int n_pairs = NBLK * (R_NB / 2);
+        constexpr int ROW_D2 = (R_NB / 2) * 18;                       // 16-byte pieces per (tile, row)
+        double2 *dst = reinterpret_cast<double2 *>(pairs);
+        constexpr int SU = 5;                                         // 2 * 16 * ROW_D2 = 4608 pieces: 4.5 per thread at 1024
+        for (int it0 = threadIdx.x; it0 < 2 * R_NB * ROW_D2; it0 += SU * blockDim.x) {
+            double2 v[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                const int itc = it < 2 * R_NB * ROW_D2 ? it : 0;
+                const int tile = itc / (R_NB * ROW_D2), rem = itc - tile * (R_NB * ROW_D2);
+                const int i = rem / ROW_D2, c = rem - i * ROW_D2;
+                const bool on = i < nb && (tile == 1 || hasA);
+                const int blk = tile == 1 ? b : (hasA ? b - 1 : 0);
+                const double *src = a.lMp + ((((int64_t)u * Nreg + B0 + (i < nb ? i : 0)) * n_pairs + blk * (R_NB / 2)) * 36 + c * 2);
+                const double2 x = make_double2(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1));
+                v[j] = on ? x : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                if (it < 2 * R_NB * ROW_D2) dst[it] = v[j];
+            }
+        }
+    } else {
         const double *rowbase = a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6;
         for (int t = threadIdx.x; t < R_NB * R_NB * 6; t += blockDim.x) {
             const int i = t / (R_NB * 6), j6 = t - i * (R_NB * 6);
@@ -482,7 +571,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
     __syncthreads();
     FCD_TRACE(trec, 1);
-    {
+    if (!pre) {
         // pair records, as in the panel role: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries
         // with 16-byte reads and writes; record (i, p) <- singles (i*16 + 2p) * 6
         const int q = threadIdx.x % 9, step = blockDim.x / 9;
@@ -995,16 +1084,37 @@ extern "C" int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t N
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
+extern "C" int fcd_gibbs_pair_table_bytes(int64_t Nreg, int64_t U, size_t *bytes) {
+    if (Nreg < 2 || U < 1 || !bytes) return FCD_ERR_ARG;
+    *bytes = (size_t)U * Nreg * ((Nreg + R_NB - 1) / R_NB * (R_NB / 2)) * 36 * sizeof(double);
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_region_pair_tables(fcd_ctx *ctx, const double *lMd, int64_t Nreg, int64_t U, double *lMp,
+                                            fcd_stream stream) {
+    if (!ctx || !lMd || !lMp) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_region_pair_tables: null pointer");
+    if (Nreg < 2 || U < 1) return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2 and U >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
+    const int64_t NP = (Nreg + R_NB - 1) / R_NB * (R_NB / 2);
+    const int64_t total = U * Nreg * NP * 9;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(region_pair_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lMd, (int)Nreg, (int)U,
+                       (int)NP, lMp);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
+extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
                                 const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream) {
-    return fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, edge_mode,
+    return fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, edge_mode,
                                (hipStream_t)stream, nullptr);
 }
 
-int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper, const uint8_t *f_state,
-                        uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep,
-                        int edge_mode, hipStream_t stream, const uint8_t *fsq) {
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+                        const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -1102,7 +1212,9 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         if (shmem < d_need) shmem = d_need;
     }
     r_step_args a;
-    a.lMd = lMd; a.hyper = hyper; a.f_S = f_S; a.r_T = r_T; a.r_Tn = r_Tn; a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
+    a.lMd = lMd; a.hyper = hyper; a.f_S = f_S;
+    a.r_T = r_T; a.r_Tn = r_Tn; a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
+    a.lMp = ctx->knobs.r_nopre ? nullptr : lMp;      // (knob r_nopre: build the records in LDS although the table is there)
     a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
     a.flags = nullptr;
     a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;

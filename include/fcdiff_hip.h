@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FCD_ABI_VERSION 1
+#define FCD_ABI_VERSION 2
 
 #define FCD_OK 0
 #define FCD_ERR_ARG (-1)         /* null pointer / non-positive size */
@@ -80,6 +80,8 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
+ *   "r_nopre"   1: ignore the pair-record table lMp (build the records in LDS at every block step)
+ *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (rejected: slower; kept for the record)
  *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
  * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
@@ -199,18 +201,26 @@ int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const do
  * ordered-pair edge id of `edge_mode` (zeros at m == n).  Built once per table build; 48*U*Nreg*Nreg bytes. */
 int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMd,
                             fcd_stream stream);
+/* Optional PAIR-RECORD table for the r step, made from lMd (once per table build): lMp (U, Nreg, NP, 9, 4), NP = 8 ceil(Nreg/16),
+ *   lMp[u][n][p][3k + k'][t + 2t'] = lMd[u][n][2p][k][t] + lMd[u][n][2p+1][k'][t']     (zero beyond Nreg)
+ * -- the records the blocked r pass otherwise builds in LDS at every block step (same additions, same bits).  Passing it
+ * to the r step (lMp != NULL) replaces the staging of single rows and the build by one copy of the tile; it costs
+ * 288 * U * Nreg * NP bytes (fcd_gibbs_pair_table_bytes: 0.30 GB at cfg3, 5.8 GB at cfg5) and three times the table
+ * traffic per pass. */
+int fcd_gibbs_pair_table_bytes(int64_t Nreg, int64_t U, size_t *bytes);
+int fcd_gibbs_region_pair_tables(fcd_ctx *ctx, const double *lMd, int64_t Nreg, int64_t U, double *lMp, fcd_stream stream);
 /* Redraw every r_nu of every chain given f, regions in order 0..Nreg-1 (systematic scan; patients
  * and chains in parallel).  With lMd (made with the SAME edge_mode) the blocked path runs: panel kernels
  * stream lMd rows through LDS, small diagonal kernels resolve the in-order dependence (only s1 - s0
  * is formed, as a sum of table differences: same conditional, one add per term).  lMd == NULL
  * selects the generic kernel that gathers from lM directly (any shape, much slower). */
-int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
+int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
                      const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                      int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream);
 /* n_sweeps x (f step, r step), sweeps numbered sweep0, sweep0+1, ...  When counts != NULL the pooled
  * statistics of the LAST sweep are stored there (see fcd_gibbs_stats). */
 int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                     const double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                     const double *lMp, const double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                      uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                      fcd_stream stream);
 /* Pooled sufficient statistics over the G chains (the all-reduce payload):
@@ -239,7 +249,8 @@ int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits
  *     - makes the packed r words of the next f pass.
  *   counts (nullable) receives the pooled statistics of the LAST sweep.
  * ceil(Nreg/16) + 4 launches per sweep at the shapes the pair-form f kernel and the blocked r pass cover. */
-int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd, double *hyper,
+int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd, const double *lMp,
+                  double *hyper,
                   uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
                   int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t mstep_every, int64_t accumulate_from,
                   int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, fcd_stream stream);

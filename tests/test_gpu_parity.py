@@ -428,16 +428,19 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kn", [{"r_persist": 0}, {"r_persist": 1}, {"r_tol": 1e30},
                                 {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
-                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}],
+                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"r_nopre": 1},
+                                {"r_nopre": 1, "r_persist": 1}, {"r_nopre": 1, "r_ub": 1}, {"r_prefetch": 1, "r_nopre": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
-                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad"])
+                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
+                              "records-built-in-LDS", "built-in-LDS-one-launch", "built-in-LDS-one-patient", "prefetch-hint"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
     Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
     re-decision paths of the fast draws (r_tol / f_tol huge: every r / f draw is repeated with the exact
-    logit / exponentials), a one-patient panel and the other forms of the f pass give the oracle's chains: several
-    blocks of 16 regions, a partial last block, odd U.  Knobs go through fcd_ctx_set_knob (nothing reads the environment).
+    logit / exponentials), a one-patient panel, the pair records copied from the table (default) or built in LDS, and
+    the other forms of the f pass give the oracle's chains: several blocks of 16 regions, a partial last block, odd U.
+    Knobs go through fcd_ctx_set_knob (nothing reads the environment).
     """
     knobs(**kn)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
