@@ -55,11 +55,12 @@ class GibbsEngine(object):
     """
 
     def __init__(self, S_B, lM, Nreg, U, n_chains, chain0=0, seed=0, edge_index="symmetric", ctx=None,
-                 region_major=True, pair_table=True):
+                 region_major=True, pair_table=False):
         """
         region_major=False keeps only lM: the generic f / r kernels run (any shape, several times slower).
-        pair_table=False leaves out the pair-record table of the r pass (0.3 GB at cfg3, 5.8 GB at cfg5): the records are
-        then built in LDS at every block step.
+        pair_table=True also makes the pair-record table of the r pass (0.3 GB at cfg3, 5.8 GB at cfg5): tiles are then
+        copied from it instead of being built in LDS at every block step.  Off by default: measured 5 % (cfg3) and 8 %
+        (cfg5) slower per block step -- the three times larger stream costs more than the build it saves.
         """
         import torch
         self.torch = torch

@@ -35,7 +35,8 @@ def main():
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
     cases = [("f full", "f", {}), ("f no-draw", "f", {"FCD_ABL_F": "2"}), ("f staging-only", "f", {"FCD_ABL_F": "3"}),
-             ("r full", "r", {}), ("r full, one-launch form", "r", {"FCD_R_PERSIST": "1"}), ("r full, one patient per panel workgroup", "r", {"FCD_R_UB": "1"}), ("r full, no empty workgroups beside D", "r", {"FCD_R_NOPAD": "1"}),
+             ("r full", "r", {}), ("r full, one-launch form", "r", {"r_persist": 1}), ("r full, one patient per panel workgroup", "r", {"r_ub": 1}), ("r full, no empty workgroups beside D", "r", {"r_nopad": 1}),
+             ("r full, pair-record table", "r", {"r_nopre": 0}), ("r panel empty, pair-record table", "r", {"r_nopre": 0, "FCD_ABL_PANEL": "5"}),
              ("r panel loads-only", "r", {"FCD_ABL_PANEL": "2"}), ("r panel staging-only", "r", {"FCD_ABL_PANEL": "3"}),
              ("r panel single rows only", "r", {"FCD_ABL_PANEL": "4"}), ("r panel empty", "r", {"FCD_ABL_PANEL": "5"}),
              ("r diag no next-thresholds", "r", {"FCD_ABL_DIAG": "1"}), ("r diag empty", "r", {"FCD_ABL_DIAG": "5"}),
@@ -45,9 +46,13 @@ def main():
     res = {name: [] for (name, _, _) in cases}
     for rnd in range(5):
         for (name, which, env) in cases:
-            for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG", "FCD_R_PERSIST", "FCD_R_UB", "FCD_R_NOPAD"):
+            for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG"):
                 os.environ.pop(k, None)
-            os.environ.update(env)
+            knobs = {"r_persist": 0, "r_ub": 0, "r_nopad": 0, "r_nopre": 1}     # (knobs go through fcd_ctx_set_knob)
+            knobs.update({k: v for (k, v) in env.items() if not k.startswith("FCD_")})
+            for (k, v) in knobs.items():
+                eng.ctx.set_knob(k, v)
+            os.environ.update({k: v for (k, v) in env.items() if k.startswith("FCD_")})
             fn = eng.f_step if which == "f" else eng.r_step
             fn(100)
             torch.cuda.synchronize()

@@ -428,24 +428,29 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kn", [{"r_persist": 0}, {"r_persist": 1}, {"r_tol": 1e30},
                                 {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
-                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"r_nopre": 1},
-                                {"r_nopre": 1, "r_persist": 1}, {"r_nopre": 1, "r_ub": 1}, {"r_prefetch": 1, "r_nopre": 1}],
+                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"_pair_table": 1},
+                                {"_pair_table": 1, "r_persist": 1}, {"_pair_table": 1, "r_ub": 1}, {"_pair_table": 1, "r_nopre": 1},
+                                {"r_prefetch": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
                               "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
-                              "records-built-in-LDS", "built-in-LDS-one-launch", "built-in-LDS-one-patient", "prefetch-hint"])
+                              "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
+                              "prefetch-hint"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
     Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
     re-decision paths of the fast draws (r_tol / f_tol huge: every r / f draw is repeated with the exact
-    logit / exponentials), a one-patient panel, the pair records copied from the table (default) or built in LDS, and
-    the other forms of the f pass give the oracle's chains: several blocks of 16 regions, a partial last block, odd U.
-    Knobs go through fcd_ctx_set_knob (nothing reads the environment).
+    logit / exponentials), a one-patient panel, the pair records built in LDS (default) or copied from the optional
+    pair-record table, and the other forms of the f pass give the oracle's chains: several blocks of 16 regions, a
+    partial last block, odd U.  Knobs go through fcd_ctx_set_knob (nothing reads the environment).
     """
+    kn = dict(kn)
+    pair_table = bool(kn.pop("_pair_table", 0))
     knobs(**kn)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 5 + N
-    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx,
+                          pair_table=pair_table)
     eng.set_hyper(m.gamma, m.pi2())
     eng.init(0.3)
     f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
