@@ -1112,8 +1112,10 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     rc = fcd_lds_attr(ctx, FCD_KA_F_DIFF, reinterpret_cast<const void *>(&gibbs_f_diff_kernel), pl.shmem);
     if (rc) return rc;
     dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
+    fcd_prof_begin(ctx, FCD_PROF_F, s);
     hipLaunchKernelGGL(gibbs_f_diff_kernel, grid, dim3(64 * wpb), pl.shmem, s, S_B, lMf, hyper, f_state, r_bits,
                        (int)Nreg, (int)U, g.C, g.GW, pl.EC, (uint32_t)chain0, seed, (uint32_t)sweep, margin);
+    fcd_prof_end(ctx, FCD_PROF_F, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
