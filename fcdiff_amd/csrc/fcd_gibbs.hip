@@ -816,14 +816,31 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
     __syncthreads();
     if (threadIdx.x == 0) sh_last = (atomicAdd(&a.acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
     __syncthreads();
-    if (sh_last && threadIdx.x == 0) {
+    if (sh_last && threadIdx.x < 64) {
+        // the five words are fetched (and reset) by five lanes at once: one memory round trip, not five in a row
+        unsigned long long mine = 0;
+        if (threadIdx.x < 5) mine = atomicExch(&a.acc[threadIdx.x], 0ull);     // read at the memory side and reset
         unsigned long long c5[5];
-        for (int i = 0; i < 4; ++i) c5[i] = atomicExch(&a.acc[i], 0ull);     // read at the memory side and reset
-        atomicExch(&a.acc[4], 0ull);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c5[i] = __shfl(mine, i, 64);
         c5[4] = (unsigned long long)G;
-        if (a.counts_out)
-            for (int i = 0; i < 8; ++i) a.counts_out[i] = i < 5 ? c5[i] : 0ull;
-        if (a.hyper) mstep_from_counts(c5, (double)NU, (double)C, a.hyper);
+        if (a.counts_out && threadIdx.x < 8) a.counts_out[threadIdx.x] = threadIdx.x < 5 ? c5[threadIdx.x] : 0ull;
+        if (a.hyper && threadIdx.x < 5) {
+            // the M-step of mstep_from_counts, one logarithm per lane: lanes 0..2 ln gamma_k, lane 3 ln(1 - pi), lane 4 ln pi
+            const double Gtot = (double)c5[4];
+            const int i = (int)threadIdx.x;
+            double v;
+            if (i < 3) {
+                const double n_f = Gtot * (double)C;
+                v = fmax((double)c5[1 + i] / n_f, 0.5 / n_f);             // fit.py:220 over chains
+            } else {
+                const double n_r = Gtot * (double)NU;
+                const double lo = 0.5 / n_r;
+                const double pi = fmin(fmax((double)c5[0] / n_r, lo), 1.0 - lo);      // fit.py:213 over chains
+                v = i == 3 ? 1.0 - pi : pi;
+            }
+            a.hyper[i < 3 ? FCD_H_LNGAMMA + i : (i == 3 ? FCD_H_LNPI0 : FCD_H_LNPI1)] = log(v);
+        }
     }
 }
 
