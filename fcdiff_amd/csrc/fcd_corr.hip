@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void corr_moments_kernel(const double *__restr
     }
 }
 
-// Gram blocks.  grid = (lower-triangle blocks of 64 x 64 regions, subjects); block = 4 waves, wave (wr, wc) owns the
+// Gram blocks.  grid = subjects x lower-triangle blocks of 64 x 64 regions (dealt per XCD, see below); block = 4 waves, wave (wr, wc) owns the
 // 2 x 2 MFMA tiles (2 wr + {0,1}, 2 wc + {0,1}) of the block.  K = T in steps of 16: the two 64 x 16 panels (rows of the
 // block's row regions / column regions, centred on the way in) are staged in LDS -- 128 contiguous bytes per region and
 // step, each element loaded once per block instead of once per tile -- double-buffered so that the loads of step k+1 fly
@@ -49,17 +49,20 @@ __global__ __launch_bounds__(256) void corr_moments_kernel(const double *__restr
 constexpr int CB = 64, CK = 16, CLD = 18;
 __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict__ ts, const double *__restrict__ mean,
                                                         const double *__restrict__ sdev, int Nreg, int T, int64_t S,
-                                                        int fisher_z, double *__restrict__ out) {
+                                                        int n_blocks, int fisher_z, double *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) double pa[2][CB * CLD], pb[2][CB * CLD];
-    // block index -> (I, J), I >= J, lower-triangular row-major like the edges themselves
-    const int t = blockIdx.x;                           // (blocks fastest: a subject's blocks run together and share its rows in
-                                                        //  L2; subjects fastest was 7 % faster at cfg3 and 17 % slower at cfg5)
+    // Workgroup -> (subject, block): consecutive workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 names the
+    // XCD class), so ALL blocks of a subject take the same class: the subject's rows (1.9 MB at cfg3, 3.8 MB at cfg5) are
+    // fetched into ONE 4 MB L2 and re-read from there by its other blocks, instead of once per XCD (a speed hint only).
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int t = jj % n_blocks;                        // block index -> (I, J), I >= J, lower-triangular row-major
+    const int64_t s = (int64_t)(jj / n_blocks) * 8 + xcd;
+    if (s >= S) return;
     int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((int64_t)I * (I + 1) / 2 > t) --I;
     while ((int64_t)(I + 1) * (I + 2) / 2 <= t) ++I;
     const int J = t - I * (I + 1) / 2;
     const bool diag = I == J;
-    const int64_t s = blockIdx.y;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     // staging: thread -> (row r of the panel, 16-byte piece p of its 128 bytes), rows r and r + 32: eight lanes cover one
@@ -190,7 +193,9 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     FCD_LAUNCH_CHECK();
     const int64_t nb = (Nreg + CB - 1) / CB;
     const int64_t blocks = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(corr_gram_kernel, dim3((unsigned)blocks, (unsigned)S), dim3(256), 0, s, ts, mean, sdev, (int)Nreg, (int)T, S,
+    const int64_t grid = (S + 7) / 8 * 8 * blocks;
+    if (grid > INT32_MAX) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: S * blocks too large");
+    hipLaunchKernelGGL(corr_gram_kernel, dim3((unsigned)grid), dim3(256), 0, s, ts, mean, sdev, (int)Nreg, (int)T, S, (int)blocks,
                        fisher_z ? 1 : 0, out);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
