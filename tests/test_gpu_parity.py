@@ -767,9 +767,13 @@ def test_gibbs_cfg5_full_size(env):
         assert np.array_equal(f_g[c0:c0 + 32], f_o) and np.array_equal(r_g[c0:c0 + 32], r_o)
 
 
-@pytest.mark.parametrize("S,N,T", [(3, 10, 200), (2, 37, 53), (5, 64, 400), (1, 2, 2), (2, 17, 1201)])
+@pytest.mark.parametrize("S,N,T", [(3, 10, 200), (2, 37, 53), (5, 64, 400), (1, 2, 2), (2, 17, 1201), (9, 130, 97), (3, 200, 64),
+                                   (2, 257, 40)])
 def test_corr_front_end_against_numpy(env, S, N, T):
-    """K_corr (fp64 MFMA Gram) vs numpy.corrcoef; oracle is third-party (not in the reference): parity unpinned."""
+    """
+    K_corr (fp64 MFMA Gram: one block, diagonal / full / partial 64 x 64 blocks, more than eight subjects, odd T) vs
+    numpy.corrcoef; oracle is third-party (not in the reference): parity unpinned.
+    """
     from fcdiff_amd.corr import correlations
     rs = np.random.RandomState(S * 1000 + N)
     base = rs.standard_normal((S, 1, T))
