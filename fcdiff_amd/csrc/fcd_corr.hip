@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void corr_moments_kernel(const double *__restr
 constexpr int CB = 64, CK = 16, CLD = 18;
 __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict__ ts, const double *__restrict__ mean,
                                                         const double *__restrict__ sdev, int Nreg, int T, int64_t S,
-                                                        int n_blocks, int fisher_z, double *__restrict__ out) {
+                                                        int n_blocks, int fisher_z, int64_t C, double *__restrict__ tmp) {
     __shared__ __attribute__((aligned(16))) double pa[2][CB * CLD], pb[2][CB * CLD];
     // Workgroup -> (subject, block): consecutive workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 names the
     // XCD class), so ALL blocks of a subject take the same class: the subject's rows (1.9 MB at cfg3, 3.8 MB at cfg5) are
@@ -171,10 +171,31 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict
                     c /= sdev[s * Nreg + m];
                     c = fmin(fmax(c, -1.0), 1.0);
                     if (fisher_z) c = atanh(c);
-                    out[(fcd_tri(n) + m) * S + s] = c;
+                    tmp[s * C + (fcd_tri(n) + m)] = c;                       // 16 lanes = 16 consecutive edges = 128 bytes
                 }
             }
         }
+}
+
+// tmp (S, C) -> out (C, S): the layout of b / bt (edge-major, subjects fastest).  The Gram kernel writes subject-major
+// rows (128 contiguous bytes per 16 lanes); written straight into (C, S) every value would be an 8-byte store 8 S bytes
+// from the next one -- 40 M partial-line writes at cfg5.  32 x 32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void corr_transpose_kernel(const double *__restrict__ tmp, int64_t S, int64_t C,
+                                                             double *__restrict__ out) {
+    __shared__ double tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, s0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8 threads
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t s = s0 + ty + j, c = c0 + tx;
+        if (s < S && c < C) tile[ty + j][tx] = tmp[s * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t c = c0 + ty + j, s = s0 + tx;
+        if (s < S && c < C) out[c * S + s] = tile[tx][ty + j];
+    }
 }
 
 }  // namespace
@@ -184,10 +205,12 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     if (!ctx || !ts || !out) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_corr_edges: null pointer");
     if (S < 1 || Nreg < 2 || T < 2) return fcd_fail(ctx, FCD_ERR_SHAPE, "need S >= 1, Nreg >= 2, T >= 2 (Nreg=%lld, T=%lld)", Nreg, T);
     if (S > 65535 || Nreg > 46340 || T > INT32_MAX) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: shape too large");
-    const int64_t rows = S * Nreg;
-    int rc = fcd_ws_reserve(ctx, (size_t)rows * 2 * sizeof(double));
+    const int64_t rows = S * Nreg, C = fcd_tri(Nreg);
+    // workspace: means and deviations of the rows, then the subject-major copy of the result (grows the context's
+    // scratch, which synchronises, the first time a shape needs it)
+    int rc = fcd_ws_reserve(ctx, ((size_t)rows * 2 + (size_t)S * C) * sizeof(double));
     if (rc) return rc;
-    double *mean = (double *)ctx->ws, *sdev = mean + rows;
+    double *mean = (double *)ctx->ws, *sdev = mean + rows, *tmp = sdev + rows;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_moments_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ts, rows, (int)T, mean, sdev);
     FCD_LAUNCH_CHECK();
@@ -196,7 +219,10 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     const int64_t grid = (S + 7) / 8 * 8 * blocks;
     if (grid > INT32_MAX) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: S * blocks too large");
     hipLaunchKernelGGL(corr_gram_kernel, dim3((unsigned)grid), dim3(256), 0, s, ts, mean, sdev, (int)Nreg, (int)T, S, (int)blocks,
-                       fisher_z ? 1 : 0, out);
+                       fisher_z ? 1 : 0, C, tmp);
+    FCD_LAUNCH_CHECK();
+    if ((C + 31) / 32 > INT32_MAX || (S + 31) / 32 > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: grid too large");
+    hipLaunchKernelGGL(corr_transpose_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((S + 31) / 32)), dim3(256), 0, s, tmp, S, C, out);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
