@@ -156,7 +156,6 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
     ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
-    ctx->knobs.f_nt = (int)knob_env("FCD_F_NT");
     ctx->knobs.r_streams = (int)knob_env("FCD_R_STREAMS");
     ctx->knobs.r_prefetch = (int)knob_env("FCD_R_PREFETCH");
     ctx->knobs.r_nopre = (int)knob_env("FCD_R_NOPRE");
@@ -252,7 +251,6 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;
     else if (!strcmp(name, "f_form")) k.f_form = (int)value;
-    else if (!strcmp(name, "f_nt")) k.f_nt = (int)value;
     else if (!strcmp(name, "r_streams")) k.r_streams = (int)value;
     else if (!strcmp(name, "r_prefetch")) k.r_prefetch = (int)value;
     else if (!strcmp(name, "r_nopre")) k.r_nopre = (int)value;

@@ -392,19 +392,14 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             if ((e & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is a multiple of 8
             const double x = fcd_u32(fcd_word(rnd, e & 3));
             bool amb;
-            int k = fcd_draw_f_fast(0.0, b1, b2, x, fabsf(margin), &amb);
+            int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
             if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
             (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
             if (fsq) {
                 // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
                 uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
-                if (margin < 0.f) {        // (experiment, knob f_nt: non-temporal stores -- the sign of margin carries the flag)
-                    __builtin_nontemporal_store((uint8_t)k, (sq + ((int64_t)wn * Nreg + wm) * 64) + (uint32_t)lane);
-                    __builtin_nontemporal_store((uint8_t)k, (sq + ((int64_t)wm * Nreg + wn) * 64) + (uint32_t)lane);
-                } else {
-                    (sq + ((int64_t)wn * Nreg + wm) * 64)[(uint32_t)lane] = (uint8_t)k;
-                    (sq + ((int64_t)wm * Nreg + wn) * 64)[(uint32_t)lane] = (uint8_t)k;
-                }
+                (sq + ((int64_t)wn * Nreg + wm) * 64)[(uint32_t)lane] = (uint8_t)k;
+                (sq + ((int64_t)wm * Nreg + wn) * 64)[(uint32_t)lane] = (uint8_t)k;
             }
             if (e + 1 < FP_EC) {
 #pragma unroll
@@ -1093,7 +1088,6 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     hipStream_t s = (hipStream_t)stream;
     float margin = FCD_DRAW_F_MARGIN;
     if ((float)ctx->knobs.f_tol > margin) margin = (float)ctx->knobs.f_tol;   // test hook: huge = every draw through fcd_draw_f
-    if (ctx->knobs.f_nt) margin = -margin;
     if (pl.form == F_PAIR || pl.form == F_PAIRX) {
         // pair forms: per-lane slot words over patients (scratch in the ctx workspace), pair records in LDS
         rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));
