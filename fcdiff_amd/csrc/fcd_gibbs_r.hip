@@ -225,6 +225,7 @@ struct r_step_args {
     uint32_t chain0, sweep;
     uint64_t seed;
     int prefetch;           // panel role: touch the next step's table rows (knob r_prefetch)
+    int direct;             // panel role: build the pair records straight from the table rows, no single rows in LDS (knob r_direct)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
 };
 
@@ -337,6 +338,49 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
                 if (it < n_d2) dst[it] = v[j];
             }
         }
+    } else if (a.direct) {
+        // pair records straight from the table rows (L2): a thread keeps one of the 9 (k, k') rows of a record and makes
+        // its four (t, t') entries from two 16-byte loads -- no single rows in LDS, no second barrier.  Up to four records
+        // per thread, all eight loads in flight together; regions beyond Nreg read as zero records.
+        const int q = threadIdx.x % 9, step = blockDim.x / 9;
+        const int k = q / 3, k2 = q - 3 * k;
+        const int total = n_pairs * UB;
+        const double *rowp[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int us = u < nu ? u : nu - 1;                        // tail chunk: replicate the last patient (never stored)
+            rowp[u] = a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6;
+        }
+        if ((int)threadIdx.x < step * 9) {
+            constexpr int BU = 4;
+            for (int pu0 = threadIdx.x / 9; pu0 < total; pu0 += BU * step) {
+                double2 a2[BU], b2[BU];
+#pragma unroll
+                for (int j = 0; j < BU; ++j) {
+                    const int pu = pu0 + j * step;
+                    const int puc = pu < total ? pu : total - 1;
+                    const int pr = puc / UB, u = puc - pr * UB;
+                    const double *row = rowp[0];
+#pragma unroll
+                    for (int uu = 1; uu < UB; ++uu)
+                        if (u == uu) row = rowp[uu];
+                    const int m0 = 2 * pr, m1 = m0 + 1;
+                    const double2 va = *reinterpret_cast<const double2 *>(row + (m0 < Nreg ? m0 : 0) * 6 + 2 * k);
+                    const double2 vb = *reinterpret_cast<const double2 *>(row + (m1 < Nreg ? m1 : 0) * 6 + 2 * k2);
+                    a2[j] = m0 < Nreg ? va : make_double2(0.0, 0.0);
+                    b2[j] = m1 < Nreg ? vb : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < BU; ++j) {
+                    const int pu = pu0 + j * step;
+                    if (pu < total) {
+                        double2 *dst = reinterpret_cast<double2 *>(pairs + pu * 36 + q * 4);        // tt = t + 2 t'
+                        dst[0] = make_double2(a2[j].x + b2[j].x, a2[j].y + b2[j].x);
+                        dst[1] = make_double2(a2[j].x + b2[j].y, a2[j].y + b2[j].y);
+                    }
+                }
+            }
+        }
     } else {
         // rows padded with zero records to a whole number of blocks: the pair build below needs no guards
         const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3;
@@ -406,7 +450,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     __syncthreads();
     FCD_TRACE(trec, 1);
     if (FCD_ABL(1, 4)) return true;       // ablation: single rows staged, no pair records
-    if (!pre) {
+    if (!pre && !a.direct) {
         // pair records: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries from two 16-byte
         // reads -- [k][t = 0, 1] of region m and [k'][t' = 0, 1] of region m+1 -- and two 16-byte writes: a third of the
         // LDS instructions of one entry per thread, and two turns through the (pair, patient) list instead of seven
@@ -1225,6 +1269,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.ncu = ctx->num_cu; a.npad = 0;
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
     a.prefetch = ctx->knobs.r_prefetch;
+    a.direct = ctx->knobs.r_direct;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);

@@ -430,11 +430,11 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
                                 {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
                                 {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"_pair_table": 1},
                                 {"_pair_table": 1, "r_persist": 1}, {"_pair_table": 1, "r_ub": 1}, {"_pair_table": 1, "r_nopre": 1},
-                                {"r_prefetch": 1}],
+                                {"r_prefetch": 1}, {"r_direct": 1}, {"r_direct": 1, "r_ub": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
                               "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
                               "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
-                              "prefetch-hint"])
+                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
@@ -542,13 +542,15 @@ def test_gibbs_sweeps_driver_equals_separate_passes(env):
     nptest.assert_array_equal(states[0][1], states[1][1])
 
 
-@pytest.mark.parametrize("N,U,G,mode", [(45, 7, 200, "symmetric"), (18, 70, 64, "symmetric"), (33, 5, 130, "reference")])
+@pytest.mark.parametrize("N,U,G,mode", [(45, 7, 200, "symmetric"), (18, 70, 64, "symmetric"), (33, 5, 130, "reference"),
+                                        (32, 3, 2048, "symmetric")])
 def test_gibbs_run_equals_call_by_call_loop(env, N, U, G, mode):
     """
     fcd_gibbs_run (one call: per sweep f pass, r pass and ONE tally launch that also carries the M-step and the packed
     r words of the next f pass) against the same loop made of the separate entry points (f step, r step, tally,
     M-step kernel): chains, hyper-parameters, marginal counters and pooled counts must be identical.  Shapes: several
-    blocks of regions with a partial chain word, the any-U f kernel, the reference edge ids (no square copy).
+    blocks of regions with a partial chain word, the any-U f kernel, the reference edge ids (no square copy), more than
+    16 chain words (two word groups per kernel).
     """
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + 2 * U)
     (n_sweeps, burn) = (5, 2)
