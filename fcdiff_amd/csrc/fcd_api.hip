@@ -148,6 +148,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->msg[0] = 0;
     ctx->n_alloc = 0;
     for (int i = 0; i < FCD_KA_N; ++i) ctx->lds_attr[i] = 0;
+    for (int i = 0; i < 3; ++i) ctx->pipe_occ[i] = -1;
     // the only place the environment is read: defaults of the knobs (fcd_ctx_set_knob changes them later)
     ctx->knobs.r_path = (int)knob_env("FCD_R_PATH");
     ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");

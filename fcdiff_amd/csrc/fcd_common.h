@@ -17,7 +17,8 @@
 // FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL: "0" / unset = default), changed afterwards only through fcd_ctx_set_knob: no
 // entry point reads the environment.
 struct fcd_knobs {
-    int r_path;        // 0: blocked r pass (default); 1: row-sequential single-launch kernel (alternative, slower)
+    int r_path;        // 0: blocked r pass, one launch per block step (default); 1: row-sequential single-launch kernel
+                       // (alternative, slower); 2: pipelined one-launch form of the blocked pass (experimental)
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_persist;     // 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; kept with its own test)
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch
@@ -32,7 +33,8 @@ struct fcd_knobs {
 
 // kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
 enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
-       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_N = FCD_KA_R_PASS + 4 };
+       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_R_PIPE = FCD_KA_R_PASS + 4,
+       FCD_KA_N = FCD_KA_R_PIPE + 4 };
 
 struct fcd_ctx {
     int device;
@@ -42,6 +44,9 @@ struct fcd_ctx {
     fcd_knobs knobs;
     long long n_alloc;             // device allocations made by this context so far (fcd_ctx_stat "n_alloc")
     size_t lds_attr[FCD_KA_N];     // largest dynamic-LDS size already set per kernel
+    int pipe_occ[3];               // pipelined r pass: workgroups per CU of the three kernel variants (-1: not asked yet) ...
+    size_t pipe_occ_shmem[3];      // ... for this much dynamic LDS
+    int pipe_occ_threads[3];       // ... and this many threads
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *side_stream; // hipStream_t + two events for the two-stream r pass (knob r_streams), made by fcd_ctx_create

@@ -288,7 +288,13 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
         // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
         const int n_d2 = ne * U * 3;
         const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
-        for (int i = threadIdx.x; i < n_d2; i += blockDim.x) single[i] = src[i];
+        // (two loads per thread in flight before the first store: a tile is at most 1536 pieces)
+        for (int i0 = threadIdx.x; i0 < n_d2; i0 += 2 * blockDim.x) {
+            const int i1 = i0 + (int)blockDim.x;
+            const double2 v0 = src[i0], v1 = src[i1 < n_d2 ? i1 : i0];
+            single[i0] = v0;
+            if (i1 < n_d2) single[i1] = v1;
+        }
     }
     __syncthreads();
     {

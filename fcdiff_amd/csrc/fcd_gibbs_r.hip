@@ -120,21 +120,29 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
     const uint8_t *__restrict__ fw = SQ ? f_state + ((int64_t)w * Nreg + n) * Nreg * 64 : f_state + (int64_t)w * C32 * 64;
     const int tn = (n * (n - 1)) >> 1;
     const uint32_t sh = 8u * (uint32_t)(lane & 3);
-    // all 16 loads first (from a clamped, always valid edge: a guard around a load is a branch and a wait per load),
+    // all loads first (from a clamped, always valid edge: a guard around a load is a branch and a wait per load),
     // the regions that do not exist or are n itself are masked afterwards
-    uint32_t k[R_NB];
+    constexpr int NB2 = SQ ? 2 : 1;          // blocks per wave: b, b + 1 (square copy: both loads in flight together)
+    uint32_t k[NB2][R_NB];
     if (SQ) {
-        // The 16 regions of the block are ONE contiguous kilobyte of the square copy: a single 16-byte load per lane
+        // The 16 regions of a block are ONE contiguous kilobyte of the square copy: a single 16-byte load per lane
         // fetches it (lane L: region L/4, chains 16 (L%4) ..), the wave's LDS slice turns it round (region j, chain
         // lane = byte j*64 + lane).  One memory instruction instead of 16.
-        const int ml = b * R_NB + (lane >> 2);
-        const uint4 q = *reinterpret_cast<const uint4 *>(fw + (uint32_t)((ml < Nreg ? ml : 0) * 64 + (lane & 3) * 16));
-        *reinterpret_cast<uint4 *>(lds_wave + lane * 16) = q;
+        uint4 q[NB2];
+#pragma unroll
+        for (int x = 0; x < NB2; ++x) {
+            const int ml = (b + x) * R_NB + (lane >> 2);
+            q[x] = *reinterpret_cast<const uint4 *>(fw + (uint32_t)((ml < Nreg ? ml : 0) * 64 + (lane & 3) * 16));
+        }
+#pragma unroll
+        for (int x = 0; x < NB2; ++x) *reinterpret_cast<uint4 *>(lds_wave + x * (R_NB * 64) + lane * 16) = q[x];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int j = 0; j < R_NB; ++j) k[j] = lds_wave[j * 64 + lane];
+        for (int x = 0; x < NB2; ++x)
+#pragma unroll
+            for (int j = 0; j < R_NB; ++j) k[x][j] = lds_wave[x * (R_NB * 64) + j * 64 + lane];
     } else {
 #pragma unroll
         for (int j = 0; j < R_NB; ++j) {
@@ -143,23 +151,43 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
             const int mm = on ? m : (n > 0 ? 0 : 1);
             const int e = (mode == FCD_EDGE_REFERENCE || n > mm) ? tn + mm : ((mm * (mm - 1)) >> 1) + n;   // fcd_pair_to_edge
             // (dword loads, each shared by 4 lanes, then the lane's byte: one-byte-per-lane loads run several times slower)
-            k[j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
+            k[0][j] = (*reinterpret_cast<const uint32_t *>(fw + (uint32_t)(e * 64 + (lane & ~3))) >> sh) & 0xffu;
         }
     }
-    uint32_t v[2] = {0u, 0u};
 #pragma unroll
-    for (int p = 0; p < R_NB / 2; ++p) {
-        const int m0 = b * R_NB + 2 * p, m1 = m0 + 1;
-        const uint32_t k0 = (m0 < Nreg && m0 != n) ? k[2 * p] : 0u;
-        const uint32_t k1 = (m1 < Nreg && m1 != n) ? k[2 * p + 1] : 0u;
-        v[p >> 2] |= ((k0 * 3u + k1) << 2) << (8 * (p & 3));
+    for (int x = 0; x < NB2; ++x) {
+        if (b + x >= NBLK) break;
+        uint32_t v[2] = {0u, 0u};
+#pragma unroll
+        for (int p = 0; p < R_NB / 2; ++p) {
+            const int m0 = (b + x) * R_NB + 2 * p, m1 = m0 + 1;
+            const uint32_t k0 = (m0 < Nreg && m0 != n) ? k[x][2 * p] : 0u;
+            const uint32_t k1 = (m1 < Nreg && m1 != n) ? k[x][2 * p + 1] : 0u;
+            v[p >> 2] |= ((k0 * 3u + k1) << 2) << (8 * (p & 3));
+        }
+        f_S[(((int64_t)w * Nreg + n) * NBLK + b + x) * 64 + lane] = make_uint2(v[0], v[1]);
     }
-    f_S[(((int64_t)w * Nreg + n) * NBLK + b) * 64 + lane] = make_uint2(v[0], v[1]);
 }
 
 // r words of (w, u, b): bit j = r_{16 b + j, u}, and the same bits one byte per pair of regions
+// (pipe: the pipelined one-launch pass follows -- clear the block's "final" mark and put the "no value yet" NaN
+// into the two panel buffers, 16 rows each, blocks 0 and 1 doing one buffer each)
+struct r_pipe_init {
+    uint32_t *marks;
+    double *P[2];
+};
+constexpr unsigned long long R_SENT = 0x7FF8DEADBEEF0001ull;      // "no panel value here yet" (a NaN no sum can produce)
 __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK,
-                                            uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S, int w, int u, int b, int lane) {
+                                            uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S, int w, int u, int b, int lane,
+                                            const r_pipe_init &pipe) {
+    if (pipe.marks) {
+        if (lane == 0) pipe.marks[((int64_t)w * U + u) * NBLK + b] = 0u;
+        if (b < 2) {                                     // (a single block never uses the second buffer)
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(pipe.P[b]) + (((int64_t)w * U + u) * R_NB) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < R_NB; ++i) dst[i * 64] = R_SENT;
+        }
+    }
     uint32_t v = 0;
 #pragma unroll
     for (int j = 0; j < R_NB; ++j) {
@@ -172,18 +200,25 @@ __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits,
     r_S[o] = spread2(v);
 }
 
-// grid (ceil(NBLK / 4), Nreg + U, GW): one wave per (w, n, b) resp. (w, u, b), no index division.
+// grid (ceil(NBLK / (4 FB)), Nreg + U, GW): one wave per (w, n, FB blocks from b) resp. (w, u, FB blocks), no index
+// division; FB = 2 with the square copy, else 1.
 // y < Nreg: f words of region n = y;  y >= Nreg: r words of patient u = y - Nreg (r_bits == nullptr: f words only).
 template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
                                                      int mode, uint2 *__restrict__ f_S, const uint64_t *__restrict__ r_bits,
-                                                     int U, uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S) {
-    const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+                                                     int U, uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S,
+                                                     const r_pipe_init pipe) {
+    constexpr int FB = SQ ? 2 : 1;
+    const int b = FB * __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
     const int y = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
-    __shared__ __attribute__((aligned(16))) uint8_t turn[4][R_NB * 64];      // one kilobyte per wave (square-copy form)
+    __shared__ __attribute__((aligned(16))) uint8_t turn[4][FB * R_NB * 64];      // one kilobyte per wave and block (square-copy form)
     if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane, turn[threadIdx.x >> 6]);
-    else pack_r_item(r_bits, Nreg, U, NBLK, r_T, r_S, (int)blockIdx.z, y - Nreg, b, lane);
+    else {
+#pragma unroll
+        for (int x = 0; x < FB; ++x)
+            if (b + x < NBLK) pack_r_item(r_bits, Nreg, U, NBLK, r_T, r_S, (int)blockIdx.z, y - Nreg, b + x, lane, pipe);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,14 +417,37 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
             }
         }
     } else {
-        // rows padded with zero records to a whole number of blocks: the pair build below needs no guards
-        const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3;
+        // rows padded with zero records to a whole number of blocks: the pair build below needs no guards.  Two loads per
+        // thread and turn, both in flight before the first is stored (addresses clamped, zeros selected afterwards: a
+        // guarded load would make every turn wait for its own trip to memory)
+        const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3, total = UB * pad_d2;
         double2 *dst = reinterpret_cast<double2 *>(single);
-        for (int it = threadIdx.x; it < UB * pad_d2; it += blockDim.x) {
-            const int u = it / pad_d2, i = it - u * pad_d2;
+        const double2 *rowp[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
             const int us = u < nu ? u : nu - 1;            // tail chunk: replicate the last patient (never stored)
-            dst[it] = i < row_d2 ? reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6)[i]
-                                 : make_double2(0.0, 0.0);
+            rowp[u] = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6);
+        }
+        constexpr int SU = 2;
+        for (int it0 = threadIdx.x; it0 < total; it0 += SU * blockDim.x) {
+            double2 v[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                const int itc = it < total ? it : total - 1;
+                const int u = itc / pad_d2, i = itc - u * pad_d2;
+                const double2 *src = rowp[0];
+#pragma unroll
+                for (int uu = 1; uu < UB; ++uu)
+                    if (u == uu) src = rowp[uu];
+                const double2 x = src[i < row_d2 ? i : 0];
+                v[j] = i < row_d2 ? x : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                if (it < total) dst[it] = v[j];
+            }
         }
     }
     const int lane = threadIdx.x & 63;
@@ -470,18 +528,24 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
         __syncthreads();
     }
     FCD_TRACE(trec, 2);
-    if (a.prefetch && st + 1 < NBLK && !pre) {
+    uint32_t pf[2] = {0u, 0u};
+    if ((a.prefetch & 1) && st + 1 < NBLK && !pre) {
         // Touch the table rows the SAME workgroup slot of the next launch will stage (region n + 16, the same patients):
         // launches deal their workgroups to the XCDs in the same order, so the lines wait in this XCD's L2 (a hint only:
-        // nothing depends on it).  One dword per 128-byte line, the value is thrown away.
+        // nothing depends on it).  One dword per 128-byte line and thread (two at most), the values are thrown away at
+        // the very end of the role: nothing waits for them here.
         const int nn = n + R_NB;
         if (nn < Nreg) {
             const int lines_per_row = (Nreg * 48 + 127) >> 7;
-            for (int it = threadIdx.x; it < UB * lines_per_row; it += blockDim.x) {
-                const int u = it / lines_per_row, ln = it - u * lines_per_row;
-                const int us = u < nu ? u : nu - 1;
-                const char *rowp = reinterpret_cast<const char *>(a.lMd + ((int64_t)(u0 + us) * Nreg + nn) * Nreg * 6);
-                (void)*reinterpret_cast<const volatile uint32_t *>(rowp + (size_t)ln * 128);     // (no use: no wait)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int it = threadIdx.x + j * (int)blockDim.x;
+                if (it < UB * lines_per_row) {
+                    const int u = it / lines_per_row, ln = it - u * lines_per_row;
+                    const int us = u < nu ? u : nu - 1;
+                    const char *rowp = reinterpret_cast<const char *>(a.lMd + ((int64_t)(u0 + us) * Nreg + nn) * Nreg * 6);
+                    pf[j] = *reinterpret_cast<const uint32_t *>(rowp + (size_t)ln * 128);
+                }
             }
         }
     }
@@ -533,6 +597,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
 #pragma unroll
     for (int u = 0; u < UB; ++u)
         if (u < nu) st_d<COH>(a.Pbuf[st & 1] + (((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane, (dpi + d[u]) - th[u]);
+    asm volatile("" ::"v"(pf[0]), "v"(pf[1]));            // keeps the prefetch loads alive; their data is long here
     FCD_TRACE(trec, 3);
     return true;
 }
@@ -544,6 +609,12 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
 // (the already redrawn bits below i, the old bits above i; the record of (i, i) is zero), compare with the
 // threshold.  All reads of a row are independent; only the 1-bit decision links one row to the next.
 constexpr int D_RECS_T = R_NB * (R_NB / 2);             // pair records of one tile
+#ifndef FCD_PF_E
+#define FCD_PF_E 3
+#endif
+#ifndef FCD_PF_F
+#define FCD_PF_F 2
+#endif
 constexpr int D_SAFE = 104;                             // records of tile 1 that end before single B starts (compact layout)
 // b = block, (u, wg) = patient, group of chain words.  wait_flag != nullptr (one-launch form): the panel sums and
 // thresholds of the block are complete once *wait_flag >= wait_need.  Returns false if that wait was abandoned.
@@ -567,6 +638,37 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 2);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
+    const bool live = w < a.GW;
+    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
+    // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
+    const uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
+    uint16_t *__restrict__ rTn = a.r_Tn + (wu * NBLK + b) * 64;
+    uint2 *__restrict__ rSn = a.r_Sn + (wu * NBLK + b) * 64;
+    const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
+    const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
+    // e_i (from the memory side: P(b) wrote them in the previous launch) and the f words are requested PF_E - 1 resp.
+    // PF_F - 1 rows ahead of the scan; the first ones leave HERE, before the tiles are staged and built (step-per-launch
+    // form: everything the scan reads was final before the launch; the one-launch form asks after its wait).
+    const uint32_t ulane = (uint32_t)lane;
+    constexpr int PF_E = FCD_PF_E, PF_F = FCD_PF_F;
+    uint32_t rold = 0, rprev = 0;
+    double ev[PF_E];
+    uint2 fa[PF_F], fb[PF_F];
+    auto first_loads = [&]() {
+        rold = rTw[ulane];
+        rprev = ld_h<COH>(rTn - (hasA ? 64 : 0) + ulane);        // (block 0: a dummy read; masked where the scan starts)
+#pragma unroll
+        for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
+#pragma unroll
+        for (int i = 0; i < PF_F - 1; ++i) {
+            const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
+            fb[i] = fro[ulane];
+            fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+        }
+    };
+    if (!COH) first_loads();
     const bool pre = a.lMp != nullptr;
     if (pre) {
         // both tiles from the pair-record table: row i of the block = 8 records (2 304 contiguous bytes) per tile
@@ -595,24 +697,35 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
             }
         }
     } else {
-        const double *rowbase = a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6;
-        for (int t = threadIdx.x; t < R_NB * R_NB * 6; t += blockDim.x) {
-            const int i = t / (R_NB * 6), j6 = t - i * (R_NB * 6);
-            const double *src = rowbase + (int64_t)i * Nreg * 6 + (int64_t)B0 * 6 + j6;
-            sB[t] = (i < nb && j6 < nb * 6) ? src[0] : 0.0;       // beyond Nreg: zero records
-            sA[t] = (hasA && i < nb) ? src[-R_NB * 6] : 0.0;
+        // single records of both tiles, 16 bytes a piece: (tile, row i, piece c of the row's 768 bytes); two pieces per
+        // thread and turn in flight together (clamped addresses, zeros selected afterwards: no load behind a branch)
+        const double2 *rowbase = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6) + B0 * 3;
+        constexpr int TILE_D2 = R_NB * R_NB * 3;
+        double2 *dA = reinterpret_cast<double2 *>(sA), *dB = reinterpret_cast<double2 *>(sB);
+        constexpr int SU = 2;
+        for (int it0 = threadIdx.x; it0 < 2 * TILE_D2; it0 += SU * blockDim.x) {
+            double2 v[SU];
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                const int itc = it < 2 * TILE_D2 ? it : 2 * TILE_D2 - 1;
+                const int tile = itc / TILE_D2, rem = itc - tile * TILE_D2;
+                const int i = rem / (R_NB * 3), c = rem - i * (R_NB * 3);
+                const bool on = i < nb && (tile == 1 ? c < nb * 3 : hasA);          // beyond Nreg: zero records
+                const int64_t off = on ? (int64_t)i * Nreg * 3 + c - (tile == 1 ? 0 : R_NB * 3) : 0;
+                const double2 x = rowbase[off];
+                v[j] = on ? x : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < SU; ++j) {
+                const int it = it0 + j * (int)blockDim.x;
+                if (it < 2 * TILE_D2) {
+                    const int tile = it / TILE_D2, rem = it - tile * TILE_D2;
+                    (tile == 1 ? dB : dA)[rem] = v[j];
+                }
+            }
         }
     }
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
-    const bool live = w < a.GW;
-    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
-    // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
-    const uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
-    uint16_t *__restrict__ rTn = a.r_Tn + (wu * NBLK + b) * 64;
-    uint2 *__restrict__ rSn = a.r_Sn + (wu * NBLK + b) * 64;
-    const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
-    const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
     __syncthreads();
     FCD_TRACE(trec, 1);
     if (!pre) {
@@ -670,21 +783,9 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     // Per region i, in order:  v = e_i (= dpi + panel sum - threshold, from P(b)) + 8 pair terms against block b-1 (its
     // r bits are final) + 8 pair terms against the own block -- redrawn bits below i, old bits above i, the record of
     // (i, i) is zero -- and the sign test.  All 16 reads of a row are independent; only the 1-bit decision links one
-    // row to the next.  e_i are requested PF_E rows ahead (they come from the memory side), the f words PF_F ahead.
-    const uint32_t ulane = (uint32_t)lane;
-    const uint32_t rold = rTw[ulane];
-    const uint32_t rprev = hasA ? ld_h<COH>(rTn - 64 + ulane) << 3 : 0u;
-    constexpr int PF_E = 3, PF_F = 2;
-    double ev[PF_E];
-    uint2 fa[PF_F], fb[PF_F];
-#pragma unroll
-    for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
-#pragma unroll
-    for (int i = 0; i < PF_F - 1; ++i) {
-        const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
-        fb[i] = fro[ulane];
-        fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
-    }
+    // row to the next.
+    if (COH) first_loads();
+    rprev = hasA ? rprev << 3 : 0u;
     uint32_t rbv[R_NB / 2];
 #pragma unroll
     for (int p = 0; p < R_NB / 2; ++p) rbv[p] = ((rold >> (2 * p)) & 3u) << 3;
@@ -755,6 +856,513 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     __builtin_amdgcn_s_setprio(0);
     FCD_TRACE(trec, 3);
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PIPELINED one-launch form (knob r_path = 2).  Same roles, same arithmetic, same chains bit for bit as the step-per-
+// launch form, but every workgroup is resident for the whole pass and walks its steps back to back:
+//   panel workgroup (row, chunk of UB patients):  P(0), P(1), ... of its region-of-the-block,
+//   in-order workgroup (patient):                 D(0), D(1), ... .
+// What crosses workgroups carries its own "ready" mark, so there are no counters, no workgroup barriers around the
+// hand-over and no read-modify-write atomics:
+//   * D(b) writes the redrawn r bytes of its block through to the memory side (agent-scope stores), waits until they
+//     are acknowledged and then sets ONE mark word per (chain word, patient, block) (pack_f_kernel cleared the marks
+//     before the pass).  A panel wave polls exactly the marks it needs -- its own chain word, its own patients, block
+//     st-2 -- and only then reads the bytes, with plain cached loads like every older block: a line of r_Sn is never
+//     touched before it is final, so no cache can hold a stale copy of it.
+//   * P(st) publishes e = (dpi + panel sum) - threshold with agent-scope stores over a NaN sentinel (R_SENT) that
+//     pack_f_kernel put there before the pass; the D wave that owns (patient, chain word) polls the value itself and
+//     puts the sentinel back once it has used it (the slot serves block st+2 next).  D orders "sentinels back, r_bits
+//     out" before its marked store (vmcnt 0), and P(st+2) writes the slot only after it has seen that mark.
+// A panel workgroup requests the table rows of its NEXT step right after it has built the records of the current one,
+// makes the thresholds while they fly and parks them in the single-row scratch (free until the next build): the
+// staging of a step costs nothing on its own.  Every poll is bounded; a wait that is given up raises the context's
+// error word (pinned host memory) and every wave drains without waiting again.
+// ---------------------------------------------------------------------------------------------
+#ifndef FCD_PIPE_PF_E
+#define FCD_PIPE_PF_E 3
+#endif
+#ifndef FCD_PIPE_PF_F
+#define FCD_PIPE_PF_F 2
+#endif
+#ifndef PIPE_SCHED_BARRIER
+#define PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+constexpr int R_POLL_LIMIT = 1 << 16;                              // x (sleep + one trip to the memory side)
+
+__device__ __forceinline__ uint32_t pair_off6(uint2 z, int p) {
+    const uint32_t w = p < 4 ? z.x : z.y;
+    const int s = 8 * (p & 3);
+    return s == 0 ? (w << 3) & 0x1F8u : (w >> (s - 3)) & 0x1F8u;
+}
+// err: the context's pinned host word.  ok: false once this wave has given up (it then never waits again).
+__device__ __forceinline__ void pipe_give_up(volatile unsigned *err, bool &ok) {
+    __hip_atomic_store(const_cast<unsigned *>(err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = false;
+}
+__device__ __forceinline__ void pipe_poll_mark(const uint32_t *mark, volatile unsigned *err, bool &ok) {
+    int spins = 0;
+    while (ok) {
+        const uint32_t v = __hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (wave-uniform address)
+        if (__builtin_amdgcn_readfirstlane((int)v) != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > R_POLL_LIMIT) pipe_give_up(err, ok);
+        else if ((spins & 255) == 0 &&
+                 __hip_atomic_load(const_cast<unsigned *>(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+            ok = false;
+    }
+    asm volatile("" ::: "memory");          // (compiler only: the loads of the bytes stay behind the poll)
+}
+// The panel value at p is not there yet (some lane still reads the sentinel): poll until it is, or give up.  Out of line
+// on purpose -- a loop with a load in it, inlined into the 16-row scan, makes the compiler wait for EVERY load in flight
+// (the next rows' requests included) at each row, i.e. one trip to the memory side per row.
+__device__ __attribute__((noinline)) double pipe_wait_e(const double *p, volatile unsigned *err) {
+    double e;
+    int spins = 0;
+    bool ok = true;
+    do {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > R_POLL_LIMIT) pipe_give_up(err, ok);
+        else if ((spins & 255) == 0 &&
+                 __hip_atomic_load(const_cast<unsigned *>(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+            ok = false;
+        e = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull);
+    return e;                                   // (still the sentinel in some lane: the wait was given up)
+}
+__device__ __forceinline__ double pipe_poll_e(const double *p, double first, volatile unsigned *err, bool &ok) {
+    double e = first;
+    if (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) {
+        e = pipe_wait_e(p, err);
+        if (__ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) ok = false;
+    }
+    return e;
+}
+
+// logit~(x) - logit(x) of the draw (idx, chain, sweep): what turns the fast threshold inside e into the exact one.  Out of
+// line on purpose: it runs for about one row in a hundred, and inlined into the 16-row scan its fp64 logarithm keeps
+// a dozen registers of constants alive across the whole loop (they spill, and every reload waits for the loads in flight).
+__device__ __attribute__((noinline)) double pipe_exact_corr(uint32_t idx, uint32_t chain, uint32_t sweep, uint64_t seed, int odd) {
+    const fcd_u4 x = fcd_philox(idx, chain, sweep, FCD_KIND_R, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double xx = odd ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y);
+    return xx > 0.0 ? fcd_logit_fast(xx) - fcd_logit(xx) : 0.0;      // (x = 0: both thresholds are -inf, v = +inf already)
+}
+
+// Panel workgroup of the pipelined form: all steps of (row, uc) for the group wg of chain words.
+template <int UB>
+__device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc, int wg, double *smem, volatile unsigned *err) {
+    const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
+    const int n_pairs = NBLK * (R_NB / 2);
+    double *pairs = smem;                                  // [n_pairs][UB][36]
+    double *single = smem + (size_t)n_pairs * UB * 36;     // [UB][16 NBLK regions * 6], zero beyond Nreg
+    const int u0 = a.u_lo + uc * UB;
+    const int nu = (a.u_lo + a.u_n - u0 < UB) ? (a.u_lo + a.u_n - u0) : UB;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ulane = (uint32_t)lane;
+    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
+    const bool live = w < a.GW;
+    const int wl = live ? w : 0;
+    const double dpi = a.hyper[FCD_H_LNPI1] - a.hyper[FCD_H_LNPI0];
+    const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3, total = UB * pad_d2;
+    constexpr int SU = 2;                                  // 16-byte pieces of the rows per thread and turn
+    bool ok = true;
+    int64_t rt[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        const int uu = u < nu ? u : nu - 1;                // tail chunk: replicate the last patient (never stored)
+        rt[u] = ((int64_t)wl * U + u0 + uu) * NBLK * 64;
+    }
+    const int64_t redrawn = a.r_Sn - a.r_S;
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    constexpr uint32_t REC = UB * 288u;
+
+    // rows of region n for the UB patients: pieces it0 + j * blockDim of [UB][pad_d2] (clamped loads, zeros beyond Nreg)
+    auto load_rows = [&](int n, int it0, double2 (&v)[SU]) {
+#pragma unroll
+        for (int j = 0; j < SU; ++j) {
+            const int it = it0 + j * (int)blockDim.x;
+            const int itc = it < total ? it : total - 1;
+            const int u = itc / pad_d2, i = itc - u * pad_d2;
+            const int us = u < nu ? u : nu - 1;
+            const double2 *src = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6);
+            const double2 x = src[i < row_d2 ? i : 0];
+            v[j] = i < row_d2 ? x : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_rows = [&](int it0, const double2 (&v)[SU]) {
+        double2 *dst = reinterpret_cast<double2 *>(single);
+#pragma unroll
+        for (int j = 0; j < SU; ++j) {
+            const int it = it0 + j * (int)blockDim.x;
+            if (it < total) dst[it] = v[j];
+        }
+    };
+    bool staged = false;                                   // the rows of the step at hand are already in the scratch
+    for (int st = 0; st < NBLK; ++st) {
+        const int rows = (Nreg - st * R_NB < R_NB) ? (Nreg - st * R_NB) : R_NB;
+        if (row >= rows) break;                            // (only the last block can be short)
+        const int n = st * R_NB + row;
+        [[maybe_unused]] const int trec = st * 1024 + (int)blockIdx.x;
+        FCD_TRACE(trec, 0);
+        FCD_TRACE_VAL(trec, 6, 1);
+        FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
+        if (!staged) {
+            for (int it0 = threadIdx.x; it0 < total; it0 += SU * blockDim.x) {
+                double2 v[SU];
+                load_rows(n, it0, v);
+                store_rows(it0, v);
+            }
+        }
+        __syncthreads();                                   // rows in place; every wave is done with the previous records
+        {
+            const int q = threadIdx.x % 9, step = blockDim.x / 9;
+            const int k = q / 3, k2 = q - 3 * k;
+            if ((int)threadIdx.x < step * 9) {
+                const int pad6 = NBLK * R_NB * 6;
+                for (int pu = threadIdx.x / 9; pu < n_pairs * UB; pu += step) {
+                    const double *su = single + (pu % UB) * pad6 + (pu / UB) * 12;      // pair (m, m+1), m = 2 (pu / UB)
+                    const double2 a2 = *reinterpret_cast<const double2 *>(su + 2 * k);
+                    const double2 b2 = *reinterpret_cast<const double2 *>(su + 6 + 2 * k2);
+                    double2 *dst = reinterpret_cast<double2 *>(pairs + pu * 36 + q * 4);
+                    dst[0] = make_double2(a2.x + b2.x, a2.y + b2.x);
+                    dst[1] = make_double2(a2.x + b2.y, a2.y + b2.y);
+                }
+            }
+        }
+        __syncthreads();                                   // records in place; the scratch is free
+        FCD_TRACE(trec, 1);
+        // the NEXT step's rows: requested now, parked in the scratch after the thresholds are made (one turn of the
+        // piece loop covers every shape whose rows fit the LDS at all: total <= 2 * blockDim pieces ... else a second turn)
+        const int rows_next = st + 1 < NBLK ? ((Nreg - (st + 1) * R_NB < R_NB) ? (Nreg - (st + 1) * R_NB) : R_NB) : 0;
+        const bool more = row < rows_next;
+        double2 nv[SU];
+        if (more) load_rows(n + R_NB, threadIdx.x, nv);
+        double th[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) th[u] = 0.0;
+        if (live) {
+            const uint32_t chain = a.chain0 + (uint32_t)w * 64u + lane;
+            fcd_u4 x = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int uu = u0 + u;
+                if (u == 0 || (uu & 1) == 0)
+                    x = fcd_philox((uint32_t)(n * ((U + 1) >> 1) + (uu >> 1)), chain, a.sweep, FCD_KIND_R, (uint32_t)a.seed,
+                                   (uint32_t)(a.seed >> 32));
+                th[u] = fcd_logit_fast((uu & 1) ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y));
+            }
+        }
+        if (more) {
+            store_rows(threadIdx.x, nv);
+            for (int it0 = threadIdx.x + SU * blockDim.x; it0 < total; it0 += SU * blockDim.x) {     // (rows longer than one turn)
+                double2 v[SU];
+                load_rows(n + R_NB, it0, v);
+                store_rows(it0, v);
+            }
+        }
+        staged = more;
+        if (!live) continue;
+        FCD_TRACE(trec, 2);
+        // The sums run over the blocks ABOVE the current one first (their r bytes are the old ones, made before the pass),
+        // then over blocks 0 .. st-2 in ascending order: the only bytes that may not be there yet -- block st-2, being
+        // redrawn by D(st-2) while this workgroup worked on step st-1 -- are asked for last, and the wave looks for
+        // their marks just before it requests them (group by group, one group ahead of the terms).
+        const int nUp = NBLK - 1 - st;                     // blocks st+1 .. NBLK-1
+        const int nLo = st >= 2 ? st - 1 : 0;              // blocks 0 .. st-2
+        const int NV = nUp + nLo;
+        const uint2 *__restrict__ fr = a.f_S + ((int64_t)wl * Nreg + n) * NBLK * 64;
+        auto blk = [&](int j) -> int {
+            const int jc = j < NV ? j : NV - 1;
+            return jc < nUp ? st + 1 + jc : jc - nUp;
+        };
+        auto rword = [&](int u, int b) -> uint2 {
+            const uint2 *base = a.r_S + (rt[u] + b * 64 + (b >= st - 1 ? (int64_t)0 : redrawn));
+            return base[ulane];
+        };
+        bool polled = st < 2;
+        auto poll_before = [&](int jlast) {                // the last entry of the list is block st-2
+            if (!polled && jlast >= NV - 1) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (u < nu) pipe_poll_mark(a.flags + ((int64_t)wl * U + u0 + u) * NBLK + (st - 2), err, ok);
+                polled = true;
+                FCD_TRACE(trec, 3);
+            }
+        };
+        double d[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) d[u] = 0.0;
+        if (FCD_ABL(1, 2)) {                    // (ablation: no terms; the hand-over stays)
+            poll_before(NV - 1);
+        } else if (NV > 0) {
+            uint2 fpv[P_GRP], rwv[P_GRP][UB];
+            poll_before(P_GRP - 1);
+#pragma unroll
+            for (int g = 0; g < P_GRP; ++g) {
+                const int b = blk(g);
+                fpv[g] = fr[b * 64 + ulane];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) rwv[g][u] = rword(u, b);
+            }
+            for (int jg = 0; jg < NV; jg += P_GRP) {
+                uint2 fpn[P_GRP], rwn[P_GRP][UB];
+                poll_before(jg + 2 * P_GRP - 1);
+#pragma unroll
+                for (int g = 0; g < P_GRP; ++g) {
+                    const int b = blk(jg + P_GRP + g);
+                    fpn[g] = fr[b * 64 + ulane];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) rwn[g][u] = rword(u, b);
+                }
+#pragma unroll
+                for (int g = 0; g < P_GRP; ++g) {
+                    if (jg + g >= NV) continue;
+                    const uint32_t base = pb_off + (uint32_t)blk(jg + g) * ((R_NB / 2) * REC);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const uint2 z = make_uint2(fpv[g].x | rwv[g][u].x, fpv[g].y | rwv[g][u].y);
+#pragma unroll
+                        for (int p = 0; p < R_NB / 2; ++p)
+                            d[u] += *(lds_cdouble *)(uintptr_t)(pair_off6(z, p) + base + (uint32_t)p * REC + (uint32_t)u * 288u);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < P_GRP; ++g) {
+                    fpv[g] = fpn[g];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) rwv[g][u] = rwn[g][u];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (u < nu) st_d<true>(a.Pbuf[st & 1] + (((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane, (dpi + d[u]) - th[u]);
+        FCD_TRACE(trec, 4);
+    }
+}
+
+// In-order workgroup of the pipelined form: all blocks of patient u for the group wg of chain words.
+__device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, double *smem, volatile unsigned *err) {
+    const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
+    const bool compact = blockDim.x == 1024;
+    double *pairs = smem;
+    double *sA = compact ? smem + D_RECS_T * 36 : smem + 2 * D_RECS_T * 36;
+    double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ulane = (uint32_t)lane;
+    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
+    const bool live = w < a.GW;
+    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    bool ok = true;
+    uint2 rpb = make_uint2(0u, 0u);                       // r bytes of block b-1 as this wave redrew them
+    for (int b = 0; b < NBLK; ++b) {
+        const int B0 = b * R_NB;
+        const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
+        const bool hasA = b > 0;
+        [[maybe_unused]] const int trec = b * 1024 + (int)blockIdx.x;
+        FCD_TRACE(trec, 0);
+        FCD_TRACE_VAL(trec, 6, 2);
+        FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
+        const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
+        const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
+        // e_i are asked for PF_E - 1 rows ahead (agent-scope loads: a trip to the memory side), the f words PF_F - 1 rows
+        // ahead (cached), and within a row the f words go first: loads return in order, so a row that waits for its f words
+        // must not find a younger e request in front of them.  (At one row ahead each of the 16 rows waited for a whole
+        // trip: 0.67 us per row with nothing else to do.)
+        constexpr int PF_E = FCD_PIPE_PF_E, PF_F = FCD_PIPE_PF_F;
+        double ev[PF_E];
+        uint2 fa[PF_F], fb[PF_F];
+        // the block's old r bytes (pack_f_kernel made them before the pass) and the first rows' e and f words: asked for
+        // BEFORE the tiles, so that they have landed by the time the staged rows have (no load is left in flight across
+        // the build, where a wait for anything is a wait for everything older)
+        uint2 rcur = a.r_S[(wu * NBLK + b) * 64 + ulane];
+#pragma unroll
+        for (int i = 0; i < PF_F - 1; ++i) {
+            const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
+            fb[i] = fro[ulane];
+            fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<true>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
+        __syncthreads();                                   // every wave is done with the previous block's records
+        FCD_TRACE(trec, 3);
+        {
+            const double2 *rowbase = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6) + B0 * 3;
+            constexpr int TILE_D2 = R_NB * R_NB * 3;
+            double2 *dA = reinterpret_cast<double2 *>(sA), *dB = reinterpret_cast<double2 *>(sB);
+            constexpr int SU = 2;
+            for (int it0 = threadIdx.x; it0 < 2 * TILE_D2; it0 += SU * blockDim.x) {
+                double2 v[SU];
+#pragma unroll
+                for (int j = 0; j < SU; ++j) {
+                    const int it = it0 + j * (int)blockDim.x;
+                    const int itc = it < 2 * TILE_D2 ? it : 2 * TILE_D2 - 1;
+                    const int tile = itc / TILE_D2, rem = itc - tile * TILE_D2;
+                    const int i = rem / (R_NB * 3), c = rem - i * (R_NB * 3);
+                    const bool on = i < nb && (tile == 1 ? c < nb * 3 : hasA);
+                    const int64_t off = on ? (int64_t)i * Nreg * 3 + c - (tile == 1 ? 0 : R_NB * 3) : 0;
+                    const double2 x = rowbase[off];
+                    v[j] = on ? x : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < SU; ++j) {
+                    const int it = it0 + j * (int)blockDim.x;
+                    if (it < 2 * TILE_D2) {
+                        const int tile = it / TILE_D2, rem = it - tile * TILE_D2;
+                        (tile == 1 ? dB : dA)[rem] = v[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        FCD_TRACE_VAL(trec, 5, wall_clock64());
+        {
+            const int q = threadIdx.x % 9, step = blockDim.x / 9;
+            const int k = q / 3, k2 = q - 3 * k;
+            const int r0 = threadIdx.x / 9;
+            const bool on = (int)threadIdx.x < step * 9;
+            auto four = [&](const double *single_tile, int rec, double2 &lo, double2 &hi) {
+                const double2 a2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 2 * k);
+                const double2 b2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 6 + 2 * k2);
+                lo = make_double2(a2.x + b2.x, a2.y + b2.x);
+                hi = make_double2(a2.x + b2.y, a2.y + b2.y);
+            };
+            auto put = [&](int rec_abs, const double2 &lo, const double2 &hi) {
+                double2 *dst = reinterpret_cast<double2 *>(pairs + rec_abs * 36 + q * 4);
+                dst[0] = lo;
+                dst[1] = hi;
+            };
+            if (on)
+                for (int rec = r0; rec < D_RECS_T; rec += step) {
+                    double2 lo, hi;
+                    four(sA, rec, lo, hi);
+                    put(rec, lo, hi);
+                }
+            __syncthreads();                                  // single A is free: tile 1 may overwrite it
+            const int safe = compact ? D_SAFE : D_RECS_T;
+            if (on)
+                for (int rec = r0; rec < safe; rec += step) {
+                    double2 lo, hi;
+                    four(sB, rec, lo, hi);
+                    put(D_RECS_T + rec, lo, hi);
+                }
+            if (compact) {
+                const int rec = D_SAFE + r0;
+                const bool mine = on && rec < D_RECS_T;
+                double2 lo = make_double2(0.0, 0.0), hi = lo;
+                if (mine) four(sB, rec, lo, hi);
+                __syncthreads();
+                if (mine) put(D_RECS_T + rec, lo, hi);
+            }
+        }
+        __syncthreads();
+        FCD_TRACE(trec, 1);
+        if (!live) continue;
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t fresh = 0;
+#pragma unroll
+        for (int i = 0; i < R_NB; ++i) {
+            if (i < nb) {
+                {
+                    const int ie = i + PF_E - 1, jf = i + PF_F - 1;
+                    const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
+                    fb[jf % PF_F] = fro[ulane];
+                    fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+                    ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
+                }
+                const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
+                // one byte per pair: (q << 2) | tt -- tile A against block b-1 (this wave's own redrawn bytes), tile B against
+                // the own block (redrawn below i, old above i; the record of (i, i) is zero)
+                const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
+                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
+                if (FCD_ABL(2, 2)) {                          // (ablation: no terms -- the wait for e stays)
+                    fresh |= (v + (double)(za.x + zb.y) > 0.0 ? 1u : 0u) << i;
+                    continue;
+                }
+                // four reads at a time (same sums, same order of additions as the step-per-launch form): the registers this
+                // saves over 16 reads in flight are what lets the f words be asked for three rows ahead
+                double sa, sb;
+                {
+                    const uint32_t ra = pb_off + (uint32_t)(i * (R_NB / 2) * 288), rb = pb_off + (uint32_t)((R_NB + i) * (R_NB / 2) * 288);
+                    auto four = [&](const uint2 &z, uint32_t rbase, int p0) -> double {
+                        double t[4];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            t[p] = *(lds_cdouble *)(uintptr_t)(pair_off6(z, p0 + p) + rbase + (uint32_t)((p0 + p) * 288));
+                        return (t[0] + t[1]) + (t[2] + t[3]);
+                    };
+                    const double a0 = four(za, ra, 0);
+                    PIPE_SCHED_BARRIER();
+                    const double a1 = four(za, ra, 4);
+                    PIPE_SCHED_BARRIER();
+                    sa = a0 + a1;
+                    const double b0 = four(zb, rb, 0);
+                    PIPE_SCHED_BARRIER();
+                    const double b1 = four(zb, rb, 4);
+                    PIPE_SCHED_BARRIER();
+                    sb = b0 + b1;
+                }
+                v = (v + sa) + sb;
+                if (__ballot(fabs(v) < a.tol) != 0ull)      // too close to call with the fast threshold in e_i: the exact one
+                    v += pipe_exact_corr((uint32_t)((B0 + i) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ulane,
+                                         a.sweep, a.seed, u & 1);
+                const uint32_t t = v > 0.0 ? 1u : 0u;
+                fresh |= t << i;
+                // region i now carries its new value for the rows below: bit (i & 1) of byte i / 2
+                constexpr uint32_t one = 1u;
+                const int sh = 8 * ((i >> 1) & 3) + (i & 1);
+                if ((i >> 1) < 4) rcur.x = (rcur.x & ~(one << sh)) | (t << sh);
+                else rcur.y = (rcur.y & ~(one << sh)) | (t << sh);
+                PIPE_SCHED_BARRIER();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R_NB; ++i) {
+            if (i < nb) {
+                const uint64_t ball = __ballot((fresh >> i) & 1u);
+                if (lane == 0) a.r_bits[((int64_t)w * Nreg + B0 + i) * U + u] = ball;
+                // the slot is free for block b + 2
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(const_cast<double *>(Pw) + i * 64 + ulane), R_SENT,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        rpb = spread2(fresh);
+        FCD_TRACE(trec, 2);
+        {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.r_Sn + (wu * NBLK + b) * 64 + ulane);
+            const unsigned long long val = (unsigned long long)rpb.x | ((unsigned long long)rpb.y << 32);
+            __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // bytes, sentinels and r_bits are out before the block is announced
+        if (lane == 0) __hip_atomic_store(a.flags + wu * NBLK + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FCD_TRACE(trec, 4);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// grid = nD + (empty workgroups beside them) + 16 nUC: workgroup (u) / (row, uc); groups of chain words one after the
+// other.  The host launches it only if every workgroup is resident at once.
+template <int UB, int WPE>
+__global__ __launch_bounds__(1024, WPE) void gibbs_r_pipe_kernel(const r_step_args a, volatile unsigned *err) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int blk = blockIdx.x;
+    if (blk < a.nD) {
+        for (int wg = 0; wg < a.nWG; ++wg) pipe_diag(a, a.u_lo + blk, wg, smem, err);
+    } else {
+        int item = blk - a.nD;
+        if (a.npad) {
+            if (blk >= a.ncu + a.nD) {
+                item -= a.npad;
+            } else if (blk >= a.ncu) {
+                return;
+            }
+        }
+        const int row = item % R_NB, uc = item / R_NB;
+        for (int wg = 0; wg < a.nWG; ++wg) pipe_panel<UB>(a, row, uc, wg, smem, err);
+    }
 }
 
 // step-per-launch form: launch s = D(s-1) workgroups, then P(s) workgroups.
@@ -1081,6 +1689,33 @@ int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool
     return FCD_OK;
 }
 
+// pipelined one-launch form: *fits = every workgroup resident at once (the occupancy is asked for once per shape)
+template <int UB, int WPE>
+int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bool launch, hipStream_t s) {
+    const void *fn = reinterpret_cast<const void *>(&gibbs_r_pipe_kernel<UB, WPE>);
+    const int slot = UB == 4 ? 2 : UB - 1;
+    {
+        int rc = fcd_lds_attr(ctx, FCD_KA_R_PIPE + slot, fn, shmem);
+        if (rc) return rc;
+    }
+    const int threads = 64 * a.wpb;
+    if (ctx->pipe_occ[slot] < 0 || ctx->pipe_occ_shmem[slot] != shmem || ctx->pipe_occ_threads[slot] != threads) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, shmem);
+        if (e != hipSuccess) return (int)e;
+        ctx->pipe_occ[slot] = per_cu;
+        ctx->pipe_occ_shmem[slot] = shmem;
+        ctx->pipe_occ_threads[slot] = threads;
+    }
+    *fits = (int64_t)ctx->pipe_occ[slot] * ctx->num_cu >= (int64_t)a.nD + a.nP;
+    if (!*fits || !launch) return FCD_OK;
+    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
+    hipLaunchKernelGGL((gibbs_r_pipe_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), shmem, s, a, ctx->dev_err);
+    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
+    FCD_LAUNCH_CHECK();
+    return FCD_OK;
+}
+
 // workspace of the blocked path: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags   (one formula for reserve and launch)
 struct r_ws_layout {
     size_t t_bytes, f_bytes, r_bytes, s_bytes, flag_words, total;
@@ -1093,7 +1728,8 @@ static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
     L.r_bytes = ((size_t)GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
     L.s_bytes = (size_t)GW * U * NBLK * 64 * sizeof(uint2);
     const int64_t nWGs = (GW + 15) / 16;
-    L.flag_words = (size_t)2 * nWGs * U * NBLK + 1;                 // (at most U chunks) + the error word
+    // one-launch form: counters of (at most U) chunks + its error word; pipelined form: one mark per (word, patient, block)
+    L.flag_words = (size_t)2 * nWGs * U * NBLK + 1 + (size_t)GW * U * NBLK;
     L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.r_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
     return L;
 }
@@ -1274,19 +1910,47 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
     const int persist = ctx->knobs.r_persist;     // EXPERIMENTAL one-launch form (slower)
+    // Pipelined one-launch form (knob r_path = 2): needs every workgroup resident at once and the pinned error word.
+    bool pipe = false;
+    r_pipe_init pinit;
+    pinit.marks = nullptr; pinit.P[0] = pinit.P[1] = nullptr;
+    if (ctx->knobs.r_path == 2 && ctx->dev_err && !persist) {
+        a.nD = (int)U;
+        a.nP = R_NB * nUC;
+        a.npad = (!ctx->knobs.r_nopad && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+        if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, false, s);
+        else if (ub == 2) rc = launch_pipe<2, 8>(ctx, a, shmem, &pipe, false, s);
+        else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, false, s);
+        if (rc) return rc;
+        if (pipe) {
+            // the marks sit behind the one-launch form's counters
+            pinit.marks = flags + ((size_t)2 * a.nWG * U * NBLK + 1);
+            pinit.P[0] = Pb[0];
+            pinit.P[1] = Pb[1];
+        }
+    }
     {
         // one launch packs the f words of every region and the r words of every patient
-        dim3 pgrid((unsigned)((NBLK + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
+        const int fb = fsq ? 2 : 1;                 // blocks per wave (pack_f_kernel)
+        dim3 pgrid((unsigned)(((NBLK + fb - 1) / fb + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
         fcd_prof_begin(ctx, FCD_PROF_PACK, s);
         if (fsq)
             hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
-                               (int)U, r_T, r_S);
+                               (int)U, r_T, r_S, pinit);
         else
             hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
-                               r_bits, (int)U, r_T, r_S);
+                               r_bits, (int)U, r_T, r_S, pinit);
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
+    if (pipe) {
+        a.flags = pinit.marks;
+        if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, true, s);
+        else if (ub == 2) rc = launch_pipe<2, 8>(ctx, a, shmem, &pipe, true, s);
+        else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, true, s);
+        return rc;
+    }
+    a.nD = 0; a.nP = 0; a.npad = 0;
     // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
     // measured 348 us against 301 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
     // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the

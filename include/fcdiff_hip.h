@@ -75,14 +75,17 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 /* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL,
  * FCD_F_FORM, FCD_R_STREAMS, read once by fcd_ctx_create; 0 = default everywhere):
- *   "r_path"    1: row-sequential single-launch r pass instead of the blocked one (alternative, slower)
+ *   "r_path"    1: row-sequential single-launch r pass instead of the blocked one (alternative, slower);
+ *               2: EXPERIMENTAL pipelined one-launch form of the blocked r pass (marks / sentinels in device memory
+ *                  instead of kernel boundaries; runs only if every workgroup is resident at once, else the
+ *                  step-per-launch form; on a par with it at BASELINE cfg 3)
  *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
  *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
  *   "r_nopre"   1: ignore the pair-record table lMp (build the records in LDS at every block step)
  *   "r_direct"  1: panel records built straight from the table rows (rejected: slower; kept for the record)
- *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (rejected: slower; kept for the record)
+ *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (no gain; kept for the record)
  *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
  * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */

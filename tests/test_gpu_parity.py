@@ -430,11 +430,13 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
                                 {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
                                 {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"_pair_table": 1},
                                 {"_pair_table": 1, "r_persist": 1}, {"_pair_table": 1, "r_ub": 1}, {"_pair_table": 1, "r_nopre": 1},
-                                {"r_prefetch": 1}, {"r_direct": 1}, {"r_direct": 1, "r_ub": 1}],
+                                {"r_prefetch": 1}, {"r_direct": 1}, {"r_direct": 1, "r_ub": 1},
+                                {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
                               "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
                               "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
-                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient"])
+                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient",
+                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
@@ -487,6 +489,37 @@ def test_gibbs_r_pass_on_two_streams(env, knobs, N, U, G, mode, ub):
     f_g, r_g = eng.export_state()
     nptest.assert_array_equal(f_g, f_o)
     nptest.assert_array_equal(r_g, r_o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,U,G,mode,ub", [(40, 9, 128, "symmetric", 0), (33, 21, 1024, "reference", 0), (70, 12, 200, "symmetric", 1),
+                                           (16, 3, 64, "symmetric", 0), (12, 2, 2048, "symmetric", 0), (97, 5, 1024, "symmetric", 0),
+                                           (200, 50, 1024, "symmetric", 0)])
+def test_gibbs_r_pass_pipelined(env, knobs, N, U, G, mode, ub):
+    """
+    Knob r_path=2: the blocked r pass in ONE launch whose workgroups hand the redrawn bits / panel sums over through
+    marks and sentinels in device memory.  Same chains as the oracle sweep after sweep: odd U, one and two patients per
+    panel workgroup, a single block, two groups of chain words, a short last block, and BASELINE cfg 3's full size
+    (where the first 64 chains are compared).  The context's error word stays clear (no wait was given up).
+    """
+    knobs(r_path=2, r_ub=ub)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    seed = 23 + N
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    Go = G if N < 200 else 64
+    f_o, r_o = env.CO.gibbs_init(Go, N, U, 0.3, seed, 64)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    n_sw = 3
+    eng.run(0, n_sw, mstep_every=0)
+    for s in range(n_sw):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 64)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g[:Go], f_o)
+    nptest.assert_array_equal(r_g[:Go], r_o)
+    eng.sweeps(n_sw, 1)          # (a call after the pass: it would report a wait that was given up)
 
 
 @pytest.mark.gpu
