@@ -261,6 +261,7 @@ struct r_step_args {
     uint64_t seed;
     int prefetch;           // panel role: touch the next step's table rows (knob r_prefetch)
     int direct;             // panel role: build the pair records straight from the table rows, no single rows in LDS (knob r_direct)
+    int stagger;            // step-per-launch form: the second workgroup of a CU starts this many x 3.5 us late (knob r_stagger)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
 };
 
@@ -314,7 +315,11 @@ __device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint
     return ok;
 }
 
-constexpr int P_GRP = 2;   // blocks of 16 regions whose state words are prefetched together: 12 VGPRs a group at 2 patients
+#ifndef FCD_PGRP1
+#define FCD_PGRP1 2
+#endif
+constexpr int P_GRP_2 = 2;           // blocks of 16 regions whose state words are prefetched together: 12 VGPRs a group at 2 patients
+constexpr int P_GRP_1 = FCD_PGRP1;   // ... with ONE patient per panel workgroup (8 VGPRs a group of two)
                            // (measured at cfg3: 1 -> 326 us per pass, 2 -> 316, 3 -> 322, 4 -> 352: register pressure)
 // role D (doubles): compact = 16 waves; (D_RECS_T - D_SAFE) * 9 rows of entries <= 1024 threads
 constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
@@ -326,6 +331,7 @@ constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
 template <int UB, bool COH>
 __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int row, int uc, int wg, double *smem,
                                              const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
+    constexpr int P_GRP = UB == 1 ? P_GRP_1 : P_GRP_2;
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const int x0 = st > 0 ? st - 1 : 0, x1 = st + 1;       // blocks left out of the sums
     const int n_pairs = NBLK * (R_NB / 2);
@@ -951,6 +957,7 @@ __device__ __attribute__((noinline)) double pipe_exact_corr(uint32_t idx, uint32
 // Panel workgroup of the pipelined form: all steps of (row, uc) for the group wg of chain words.
 template <int UB>
 __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc, int wg, double *smem, volatile unsigned *err) {
+    constexpr int P_GRP = UB == 1 ? P_GRP_1 : P_GRP_2;
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const int n_pairs = NBLK * (R_NB / 2);
     double *pairs = smem;                                  // [n_pairs][UB][36]
@@ -1388,6 +1395,10 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
         }
         const int rows = (a.Nreg - a.s * R_NB < R_NB) ? (a.Nreg - a.s * R_NB) : R_NB;
         const int nUC = (a.u_n + UB - 1) / UB;
+        // (knob r_stagger, for launches of several rounds of workgroups: the second workgroup of every CU starts late, so
+        // that the two of a CU -- and the ones that follow them -- are not in the same phase at the same time)
+        if (a.stagger > 0 && blk >= a.ncu && blk < 2 * a.ncu)
+            for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
         r_role_panel<UB, false>(a, a.s, item % rows, (item / rows) % nUC, item / (rows * nUC), smem, nullptr, 0u, nullptr, nullptr);
     }
 }
@@ -1906,6 +1917,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
     a.prefetch = ctx->knobs.r_prefetch;
     a.direct = ctx->knobs.r_direct;
+    a.stagger = ctx->knobs.r_stagger;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
