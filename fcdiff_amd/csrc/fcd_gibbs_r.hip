@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void region_pair_tables_kernel(const double *_
 // (extract the byte, shift-add the tile base).
 //   f_S[w][n][b][lane]   uint2: byte p (x: pairs 0-3, y: pairs 4-7) = q << 2 of block b
 //   r_S[w][u][b][lane]   uint2: byte p = tt of block b, before the pass; r_Sn likewise, the blocks redrawn in the pass
-//   r_T[w][u][b][lane]   uint16: bit j = r_{16 b + j, u} (what the in-order part D reads and writes); r_Tn likewise
+//   (the in-order part D reads the same bytes: the old ones of its own block from r_S, the redrawn ones of the block before from r_Sn)
 // (f of a region beyond Nreg or of m == n counts as 0; those table records are zero.)
 // ---------------------------------------------------------------------------------------------
 // 8 two-bit fields of x -> the low two bits of 8 bytes (x: fields 0-3, y: fields 4-7)
@@ -109,6 +109,13 @@ __device__ __forceinline__ uint32_t pair_off(uint2 z, int p) {
     const uint32_t w = p < 4 ? z.x : z.y;
     const int s = 8 * (p & 3);
     return s == 0 ? (w << 3) & 0x7F8u : (w >> (s - 3)) & 0x7F8u;
+}
+
+// the same from 6 bits of the byte (q << 2 | tt <= 35): whatever sits in bits 6-7 is ignored
+__device__ __forceinline__ uint32_t pair_off6(uint2 z, int p) {
+    const uint32_t w = p < 4 ? z.x : z.y;
+    const int s = 8 * (p & 3);
+    return s == 0 ? (w << 3) & 0x1F8u : (w >> (s - 3)) & 0x1F8u;
 }
 
 // (w, n, b) wave-uniform: all index arithmetic is scalar, 32-bit (C * 64 fits an int, checked by the host)
@@ -178,7 +185,7 @@ struct r_pipe_init {
 };
 constexpr unsigned long long R_SENT = 0x7FF8DEADBEEF0001ull;      // "no panel value here yet" (a NaN no sum can produce)
 __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK,
-                                            uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S, int w, int u, int b, int lane,
+                                            uint2 *__restrict__ r_S, int w, int u, int b, int lane,
                                             const r_pipe_init &pipe) {
     if (pipe.marks) {
         if (lane == 0) pipe.marks[((int64_t)w * U + u) * NBLK + b] = 0u;
@@ -196,7 +203,6 @@ __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits,
         v |= (m < Nreg ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
     const int64_t o = (((int64_t)w * U + u) * NBLK + b) * 64 + lane;
-    r_T[o] = (uint16_t)v;
     r_S[o] = spread2(v);
 }
 
@@ -206,7 +212,7 @@ __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits,
 template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
                                                      int mode, uint2 *__restrict__ f_S, const uint64_t *__restrict__ r_bits,
-                                                     int U, uint16_t *__restrict__ r_T, uint2 *__restrict__ r_S,
+                                                     int U, uint2 *__restrict__ r_S,
                                                      const r_pipe_init pipe) {
     constexpr int FB = SQ ? 2 : 1;
     const int b = FB * __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
     else {
 #pragma unroll
         for (int x = 0; x < FB; ++x)
-            if (b + x < NBLK) pack_r_item(r_bits, Nreg, U, NBLK, r_T, r_S, (int)blockIdx.z, y - Nreg, b + x, lane, pipe);
+            if (b + x < NBLK) pack_r_item(r_bits, Nreg, U, NBLK, r_S, (int)blockIdx.z, y - Nreg, b + x, lane, pipe);
     }
 }
 
@@ -244,10 +250,8 @@ struct r_step_args {
     const double *lMd, *hyper;
     const double *lMp;      // pair-record table (nullable): tiles are copied from it instead of being built in LDS
     const uint2 *f_S;       // f pair bytes (q << 2)
-    const uint16_t *r_T;    // r words before the pass (pack_r): what the blocks above the current one still hold
-    uint16_t *r_Tn;         // r words redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
-    const uint2 *r_S;       // the same two, one byte per pair of regions (what the panel role reads)
-    uint2 *r_Sn;
+    const uint2 *r_S;       // r bytes (one per pair of regions) before the pass (pack_r): what the blocks above the current one still hold
+    uint2 *r_Sn;            // r bytes redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
     uint64_t *r_bits;
     double *Pbuf[2];        // e = (dpi + panel sum) - threshold: P(s) writes [s & 1], D(s) reads it
     uint32_t *flags;        // one-launch form: cntP[wg][uc][s] | cntD[wg][uc][s] | error word; else nullptr
@@ -649,8 +653,6 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     const bool live = w < a.GW;
     const int64_t wu = (int64_t)(live ? w : 0) * U + u;
     // wave-uniform bases (scalar registers) + the lane: no per-lane 64-bit pointers held across the scan
-    const uint16_t *__restrict__ rTw = a.r_T + (wu * NBLK + b) * 64;
-    uint16_t *__restrict__ rTn = a.r_Tn + (wu * NBLK + b) * 64;
     uint2 *__restrict__ rSn = a.r_Sn + (wu * NBLK + b) * 64;
     const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
     const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
@@ -659,12 +661,21 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     // form: everything the scan reads was final before the launch; the one-launch form asks after its wait).
     const uint32_t ulane = (uint32_t)lane;
     constexpr int PF_E = FCD_PF_E, PF_F = FCD_PF_F;
-    uint32_t rold = 0, rprev = 0;
+    uint2 rcur = make_uint2(0u, 0u), rpb = make_uint2(0u, 0u);      // r bytes (one per pair: tt) of the own block (old) / of block b-1 (redrawn)
     double ev[PF_E];
     uint2 fa[PF_F], fb[PF_F];
     auto first_loads = [&]() {
-        rold = rTw[ulane];
-        rprev = ld_h<COH>(rTn - (hasA ? 64 : 0) + ulane);        // (block 0: a dummy read; masked where the scan starts)
+        rcur = a.r_S[(wu * NBLK + b) * 64 + ulane];
+        {
+            const uint2 *src = rSn - (hasA ? 64 : 0) + ulane;       // (block 0: a dummy read; masked where the scan starts)
+            if (COH) {
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                rpb = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+            } else {
+                rpb = *src;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
 #pragma unroll
@@ -785,16 +796,14 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     if (!live || FCD_ABL(2, 3)) return true;
     // The scan is the serial chain of the pass (one per patient): its waves go ahead of the panel waves that share the CU.
     __builtin_amdgcn_s_setprio(3);
-    const char *pa = reinterpret_cast<const char *>(pairs);
     // Per region i, in order:  v = e_i (= dpi + panel sum - threshold, from P(b)) + 8 pair terms against block b-1 (its
     // r bits are final) + 8 pair terms against the own block -- redrawn bits below i, old bits above i, the record of
     // (i, i) is zero -- and the sign test.  All 16 reads of a row are independent; only the 1-bit decision links one
     // row to the next.
     if (COH) first_loads();
-    rprev = hasA ? rprev << 3 : 0u;
-    uint32_t rbv[R_NB / 2];
-#pragma unroll
-    for (int p = 0; p < R_NB / 2; ++p) rbv[p] = ((rold >> (2 * p)) & 3u) << 3;
+    if (!hasA) rpb = make_uint2(0u, 0u);
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
     uint32_t fresh = 0;
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
@@ -809,23 +818,22 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
             const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
             double v = ev[i % PF_E];
             if (FCD_ABL(2, 2)) { fresh |= (v + (double)(fwa.x + fwb.y) > 0.0 ? 1u : 0u) << i; continue; }
+            // one byte per pair, (q << 2) | tt, OR-ed once per tile; a term = 6 bits of it x 8 + the record's place in the
+            // tile (an LDS-space address: scalar base + lane offset + immediate)
+            const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
             double sa, sb;
             {
                 double ta[R_NB / 2];
 #pragma unroll
-                for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t adA = pair_off(fwa, p) | ((rprev >> (2 * p)) & 24u);
-                    ta[p] = *reinterpret_cast<const double *>(pa + adA + (uint32_t)((i * (R_NB / 2) + p) * 288));
-                }
+                for (int p = 0; p < R_NB / 2; ++p)
+                    ta[p] = *(lds_cdouble *)(uintptr_t)(pair_off6(za, p) + pb_off + (uint32_t)((i * (R_NB / 2) + p) * 288));
                 sa = ((ta[0] + ta[1]) + (ta[2] + ta[3])) + ((ta[4] + ta[5]) + (ta[6] + ta[7]));
             }
             {
                 double tb[R_NB / 2];
 #pragma unroll
-                for (int p = 0; p < R_NB / 2; ++p) {
-                    const uint32_t adB = pair_off(fwb, p) | rbv[p];
-                    tb[p] = *reinterpret_cast<const double *>(pa + adB + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
-                }
+                for (int p = 0; p < R_NB / 2; ++p)
+                    tb[p] = *(lds_cdouble *)(uintptr_t)(pair_off6(zb, p) + pb_off + (uint32_t)(((R_NB + i) * (R_NB / 2) + p) * 288));
                 sb = ((tb[0] + tb[1]) + (tb[2] + tb[3])) + ((tb[4] + tb[5]) + (tb[6] + tb[7]));
             }
             v = (v + sa) + sb;
@@ -839,11 +847,15 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
             }
             const uint32_t t = v > 0.0 ? 1u : 0u;
             fresh |= t << i;
-            // region i now carries its new value for the rows below
-            rbv[i >> 1] = (rbv[i >> 1] & ~(8u << (i & 1))) | (t << (3 + (i & 1)));
+            // region i now carries its new value for the rows below: bit (i & 1) of byte i / 2
+            {
+                constexpr uint32_t one = 1u;
+                const int sh = 8 * ((i >> 1) & 3) + (i & 1);
+                if ((i >> 1) < 4) rcur.x = (rcur.x & ~(one << sh)) | (t << sh);
+                else rcur.y = (rcur.y & ~(one << sh)) | (t << sh);
+            }
         }
     }
-    st_h<COH>(rTn + ulane, (uint16_t)fresh);
     {
         // the same bits, one byte per pair, for the panel role (a 64-bit agent-scope store in the one-launch form)
         const uint2 sp = spread2(fresh);
@@ -896,11 +908,6 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 #endif
 constexpr int R_POLL_LIMIT = 1 << 16;                              // x (sleep + one trip to the memory side)
 
-__device__ __forceinline__ uint32_t pair_off6(uint2 z, int p) {
-    const uint32_t w = p < 4 ? z.x : z.y;
-    const int s = 8 * (p & 3);
-    return s == 0 ? (w << 3) & 0x1F8u : (w >> (s - 3)) & 0x1F8u;
-}
 // err: the context's pinned host word.  ok: false once this wave has given up (it then never waits again).
 __device__ __forceinline__ void pipe_give_up(volatile unsigned *err, bool &ok) {
     __hip_atomic_store(const_cast<unsigned *>(err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1727,21 +1734,20 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
     return FCD_OK;
 }
 
-// workspace of the blocked path: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags   (one formula for reserve and launch)
+// workspace of the blocked path: P[2] | f_S | r_S | r_Sn | flags   (one formula for reserve and launch)
 struct r_ws_layout {
-    size_t t_bytes, f_bytes, r_bytes, s_bytes, flag_words, total;
+    size_t t_bytes, f_bytes, s_bytes, flag_words, total;
 };
 static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
     r_ws_layout L;
     const int64_t NBLK = (Nreg + R_NB - 1) / R_NB;
     L.t_bytes = (size_t)GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
     L.f_bytes = (size_t)GW * Nreg * NBLK * 64 * sizeof(uint2);
-    L.r_bytes = ((size_t)GW * U * NBLK * 64 * sizeof(uint16_t) + 255) / 256 * 256;
     L.s_bytes = (size_t)GW * U * NBLK * 64 * sizeof(uint2);
     const int64_t nWGs = (GW + 15) / 16;
     // one-launch form: counters of (at most U) chunks + its error word; pipelined form: one mark per (word, patient, block)
     L.flag_words = (size_t)2 * nWGs * U * NBLK + 1 + (size_t)GW * U * NBLK;
-    L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.r_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
+    L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
     return L;
 }
 static size_t r_ws_seq(int64_t Nreg, int64_t U, int64_t GW) {
@@ -1868,10 +1874,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
             return FCD_OK;
         }
     }
-    // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | r_T | r_Tn | flags
+    // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | flags
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
     const r_ws_layout L = r_ws_blocked(Nreg, U, g.GW);
-    const size_t t_bytes = L.t_bytes, f_bytes = L.f_bytes, r_bytes = L.r_bytes, s_bytes = L.s_bytes;
+    const size_t t_bytes = L.t_bytes, f_bytes = L.f_bytes, s_bytes = L.s_bytes;
     if ((int64_t)g.GW * Nreg * NBLK > INT32_MAX / 4 || g.C * 64 > INT32_MAX || (int64_t)g.GW * U * R_NB > INT32_MAX / 64)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r step: Nreg=%lld with G=%lld exceeds 32-bit item indices", Nreg, G);
     rc = fcd_ws_reserve(ctx, L.total);
@@ -1883,8 +1889,6 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     wsp += f_bytes;
     uint2 *r_S = (uint2 *)wsp, *r_Sn = (uint2 *)(wsp + s_bytes);
     wsp += 2 * s_bytes;
-    uint16_t *r_T = (uint16_t *)wsp, *r_Tn = (uint16_t *)(wsp + r_bytes);
-    wsp += 2 * r_bytes;
     uint32_t *flags = (uint32_t *)wsp;
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
@@ -1904,7 +1908,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     }
     r_step_args a;
     a.lMd = lMd; a.hyper = hyper; a.f_S = f_S;
-    a.r_T = r_T; a.r_Tn = r_Tn; a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
+    a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
     a.lMp = ctx->knobs.r_nopre ? nullptr : lMp;      // (knob r_nopre: build the records in LDS although the table is there)
     a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
     a.flags = nullptr;
@@ -1948,10 +1952,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         fcd_prof_begin(ctx, FCD_PROF_PACK, s);
         if (fsq)
             hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
-                               (int)U, r_T, r_S, pinit);
+                               (int)U, r_S, pinit);
         else
             hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
-                               r_bits, (int)U, r_T, r_S, pinit);
+                               r_bits, (int)U, r_S, pinit);
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
