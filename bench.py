@@ -17,6 +17,10 @@ counters: the loop is fcdiff_amd.gibbs.run_chains, the one UnsharedRegionFit(met
 One posterior sample = one sweep of one chain; value = chains * steps / time over all ranks.
 The likelihood tables depend only on (mu, sigma, eta, epsilon), which this loop holds fixed, so they are
 built once before the timed region (and timed separately: "lik_tables").
+Before the W warm-up steps the chains run `--settle` untimed sweeps (default 64; config.settle_sweeps): burn-in from the
+random initial state, and the device reaches its steady state -- measured on the box, the first ~25 sweeps after
+start-up take ~5 % longer than all later ones (20 timed steps: 0.459 ms after 5 untimed sweeps, 0.435-0.438 ms after
+50, 200 or 1000; profiles/fixed_cost.py: the loop itself has no constant cost per call).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step (the r block step or the f pass,
 whichever took longer in total), timed with HIP events on the launch stream; algorithmic bytes per launch follow
@@ -46,6 +50,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=64,
+                    help="untimed sweeps right after the chains are initialised, before the W warm-up steps: burn-in, and the "
+                         "device reaches its steady state (measured: the first ~25 sweeps after start-up run ~5 %% slower)")
     ap.add_argument("--nreg", type=int, default=200)
     ap.add_argument("--subjects", type=int, default=100)
     ap.add_argument("--chains-per-gpu", type=int, default=1024)
@@ -129,11 +136,14 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region: W warm-up steps, then exactly K steps of the sampler loop ----
-    run_chains(eng, args.warmup, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
+    s_w = args.settle                                                     # first warm-up sweep
+    if args.settle > 0:
+        run_chains(eng, args.settle, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
+    run_chains(eng, args.warmup, sweep0=s_w, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
     fence()
     n_alloc0 = ctx.stat("n_alloc")
     t0 = time.perf_counter()
-    run_chains(eng, args.steps, sweep0=args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
+    run_chains(eng, args.steps, sweep0=s_w + args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
     fence()
     elapsed = time.perf_counter() - t0
     allocs_in_timed_region = ctx.stat("n_alloc") - n_alloc0
@@ -160,7 +170,7 @@ def main():
     # pass by pass, with the pairs enabled, and only that second pass feeds the per-kernel numbers.
     ev = {"f": [], "r": [], "t": []}
     ctx.prof_enable(True)
-    for s in range(args.warmup + args.steps, args.warmup + 2 * args.steps):
+    for s in range(s_w + args.warmup + args.steps, s_w + args.warmup + 2 * args.steps):
         a, b_, c, d = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         a.record()
         eng.f_step(s)
@@ -250,6 +260,7 @@ def main():
                                "(pi,gamma) M-step every %d sweep(s), fixed tables" % (cfg_name, Nreg, C, H, U, G, args.mstep_every),
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
                    "mstep_lag": lag, "ranks_seen": ranks_seen, "allreduce_us": allreduce_us,
+                   "settle_sweeps": args.settle,     # untimed, before the W warm-up steps (burn-in; device steady state)
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
         "roofline": roof,
         "sweep_hbm": {"algorithmic_bytes_per_sweep": sweep_bytes, "achieved_GBps": sweep_bytes / (elapsed / args.steps) / 1e9,
