@@ -29,12 +29,13 @@ struct fcd_knobs {
     int r_prefetch;    // 1: panel workgroups touch the table rows of the next block step (L2 warm-up hint)
     int r_stagger;     // > 0: the second panel workgroup of every CU starts r_stagger x 3.5 us late (launches of several rounds)
     int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
-    int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
+    int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form;
+                       // 4: triple records (U <= 72)
 };
 
 // kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
 enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
-       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_R_PIPE = FCD_KA_R_PASS + 4,
+       FCD_KA_F_TRI = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_STEP = FCD_KA_F_TRI + 6, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_R_PIPE = FCD_KA_R_PASS + 4,
        FCD_KA_N = FCD_KA_R_PIPE + 4 };
 
 struct fcd_ctx {

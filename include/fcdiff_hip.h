@@ -87,7 +87,8 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_direct"  1: panel records built straight from the table rows (rejected: slower; kept for the record)
  *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (no gain; kept for the record)
  *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
- *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
+ *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form;
+ *               4: records for triples of patients (U <= 72)
  * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
 int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value);
 /* Counters of the context: "n_alloc" device allocations made so far, "ws_bytes", "fsq_bytes". */

@@ -428,12 +428,14 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kn", [{"r_persist": 0}, {"r_persist": 1}, {"r_tol": 1e30},
                                 {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
-                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_nopad": 1}, {"_pair_table": 1},
+                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"f_form": 4}, {"f_form": 4, "f_tol": 1e30},
+                                {"r_nopad": 1}, {"_pair_table": 1},
                                 {"_pair_table": 1, "r_persist": 1}, {"_pair_table": 1, "r_ub": 1}, {"_pair_table": 1, "r_nopre": 1},
                                 {"r_prefetch": 1}, {"r_direct": 1}, {"r_direct": 1, "r_ub": 1},
                                 {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
-                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
+                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel",
+                              "triple-f-kernel", "triple-f-kernel-exact", "no-pad",
                               "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
                               "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient",
                               "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
@@ -548,6 +550,39 @@ def test_gibbs_sweeps_odd_shapes(env, N, U, G, mode):
     f_g, r_g = eng.export_state()
     nptest.assert_array_equal(f_g, f_o)
     nptest.assert_array_equal(r_g, r_o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,U,G", [(9, 1, 64), (9, 2, 64), (12, 3, 70), (10, 4, 64), (21, 7, 130), (14, 12, 64), (14, 13, 64),
+                                   (40, 50, 1024), (17, 64, 128), (13, 72, 64), (33, 25, 2048)])
+def test_gibbs_f_pass_triple_records(env, knobs, N, U, G):
+    """
+    Knob f_form=4: the f pass with records for TRIPLES of patients (one 16-byte LDS read per three patients) walks the
+    oracle's chains through fcd_gibbs_run (whose tally makes the 12-patients-per-word slot sources of the next pass) and
+    through the separate entry points (pack_ru_kernel): one, two and three patients, a last triple of one and two, one to
+    six slot words, cfg3's U at 1024 chains, two groups of chain words.
+    """
+    knobs(f_form=4)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + 3 * U)
+    seed = 31 + N
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for fused in (True, False):
+        eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, ctx=env.ctx)
+        eng.set_hyper(m.gamma, m.pi2())
+        eng.init(0.3)
+        f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
+        if fused:
+            eng.run(0, 3, mstep_every=0)
+        else:
+            for s in range(3):
+                eng.f_step(s)
+                eng.r_step(s)
+        for s in range(3):
+            env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
+            env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES["symmetric"], 64)
+        f_g, r_g = eng.export_state()
+        nptest.assert_array_equal(f_g, f_o)
+        nptest.assert_array_equal(r_g, r_o)
 
 
 @pytest.mark.gpu
