@@ -192,13 +192,16 @@ def main():
     kern = {k: {"total_ms": v[0], "launches": v[1], "avg_launch_ms": v[0] / max(v[1], 1)} for (k, v) in prof.items()
             if k != "lik_kernel" and v[1] > 0}
     f_name = "gibbs_f_pair_kernel"        # event slot of the f pass (either pair form)
-    r_name = "gibbs_r_step_kernel"
+    r_name = "gibbs_r_step_kernel"        # event slot of the r pass's main launches: one per block step, or ...
+    if r_name in kern and kern[r_name]["launches"] == args.steps:
+        kern["gibbs_r_pipe_kernel"] = kern.pop(r_name)        # ... ONE per pass: the pipelined one-launch form ran
+        r_name = "gibbs_r_pipe_kernel"
     # algorithmic bytes, SURVEY.md section 8d (u8 state): lM once per pass + state
     f_bytes = 72 * C * U + 24 * C + G * (C + Nreg * U)
     r_bytes = 72 * C * U + G * (C + 2 * Nreg * U)
     n_step = max(kern[r_name]["launches"] // max(args.steps, 1), 1) if r_name in kern else 1   # step launches per pass
     per_launch_bytes = {f_name: f_bytes,
-                        # a step launch serves 16 of the Nreg regions' rows of the r pass
+                        # a step launch serves 16 of the Nreg regions' rows of the r pass (the pipelined form: all of them)
                         r_name: r_bytes / n_step}
     have = [k for k in (f_name, r_name) if k in kern]
     roof = None

@@ -17,8 +17,9 @@
 // FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL: "0" / unset = default), changed afterwards only through fcd_ctx_set_knob: no
 // entry point reads the environment.
 struct fcd_knobs {
-    int r_path;        // 0: blocked r pass, one launch per block step (default); 1: row-sequential single-launch kernel
-                       // (alternative, slower); 2: pipelined one-launch form of the blocked pass (experimental)
+    int r_path;        // 0: blocked r pass -- pipelined one-launch form where its grid fits the device at once, else one launch
+                       // per block step; 1: row-sequential single-launch kernel (alternative, slower); 2: as 0;
+                       // 3: one launch per block step always
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_persist;     // 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; kept with its own test)
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch

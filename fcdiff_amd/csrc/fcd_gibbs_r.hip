@@ -877,7 +877,8 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// PIPELINED one-launch form (knob r_path = 2).  Same roles, same arithmetic, same chains bit for bit as the step-per-
+// PIPELINED one-launch form (the default wherever all its workgroups fit the device at once; knob r_path = 3 keeps the
+// step-per-launch form).  Same roles, same arithmetic, same chains bit for bit as the step-per-
 // launch form, but every workgroup is resident for the whole pass and walks its steps back to back:
 //   panel workgroup (row, chunk of UB patients):  P(0), P(1), ... of its region-of-the-block,
 //   in-order workgroup (patient):                 D(0), D(1), ... .
@@ -1926,11 +1927,12 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
     const int persist = ctx->knobs.r_persist;     // EXPERIMENTAL one-launch form (slower)
-    // Pipelined one-launch form (knob r_path = 2): needs every workgroup resident at once and the pinned error word.
+    // Pipelined one-launch form (the default where it fits; knob r_path = 3 keeps the step-per-launch form): needs every
+    // workgroup resident at once and the pinned error word.
     bool pipe = false;
     r_pipe_init pinit;
     pinit.marks = nullptr; pinit.P[0] = pinit.P[1] = nullptr;
-    if (ctx->knobs.r_path == 2 && ctx->dev_err && !persist) {
+    if ((ctx->knobs.r_path == 0 || ctx->knobs.r_path == 2) && ctx->dev_err && !persist && ctx->knobs.r_streams != 2) {
         a.nD = (int)U;
         a.nP = R_NB * nUC;
         a.npad = (!ctx->knobs.r_nopad && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;

@@ -75,10 +75,9 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 /* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL,
  * FCD_F_FORM, FCD_R_STREAMS, read once by fcd_ctx_create; 0 = default everywhere):
- *   "r_path"    1: row-sequential single-launch r pass instead of the blocked one (alternative, slower);
- *               2: EXPERIMENTAL pipelined one-launch form of the blocked r pass (marks / sentinels in device memory
- *                  instead of kernel boundaries; runs only if every workgroup is resident at once, else the
- *                  step-per-launch form; on a par with it at BASELINE cfg 3)
+ *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
+ *                  kernel boundaries) wherever every workgroup is resident at once, else one launch per block step;
+ *               1: row-sequential single-launch r pass (alternative, slower); 2: as 0; 3: one launch per block step always
  *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
  *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch

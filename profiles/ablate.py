@@ -48,7 +48,7 @@ def main():
         for (name, which, env) in cases:
             for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG"):
                 os.environ.pop(k, None)
-            knobs = {"r_persist": 0, "r_ub": 0, "r_nopad": 0, "r_nopre": 1}     # (knobs go through fcd_ctx_set_knob)
+            knobs = {"r_persist": 0, "r_ub": 0, "r_nopad": 0, "r_nopre": 1, "r_path": 3}     # (fcd_ctx_set_knob; step-per-launch form)
             knobs.update({k: v for (k, v) in env.items() if not k.startswith("FCD_")})
             for (k, v) in knobs.items():
                 eng.ctx.set_knob(k, v)

@@ -33,7 +33,7 @@ def main():
     for s in range(3):
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
-    cases = [("step-per-launch form, full", {"r_path": 0}), ("pipelined, full", {"r_path": 2}),
+    cases = [("step-per-launch form, full", {"r_path": 3}), ("pipelined, full", {"r_path": 2}),
              ("pipelined, no panel terms", {"r_path": 2, "FCD_ABL_PANEL": "2"}),
              ("pipelined, no in-order terms", {"r_path": 2, "FCD_ABL_DIAG": "2"}),
              ("pipelined, neither", {"r_path": 2, "FCD_ABL_PANEL": "2", "FCD_ABL_DIAG": "2"})]

@@ -28,7 +28,9 @@ def main():
     fit.model, fit.b, fit.bt = model, b, bt
     fit._init_lps(Nreg, H, U)
     fit._update_lps()
-    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, seed=1, ctx=fit._context())
+    ctx = fit._context()
+    ctx.set_knob("r_path", 3)            # the step-per-launch form (the pipelined one: trace_pipe.py)
+    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, seed=1, ctx=ctx)
     eng.set_hyper(model.gamma, model.pi2())
     eng.init(float(model.pi))
     for s in range(3):

@@ -426,18 +426,20 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kn", [{"r_persist": 0}, {"r_persist": 1}, {"r_tol": 1e30},
-                                {"r_persist": 1, "r_tol": 1e30}, {"r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
+@pytest.mark.parametrize("kn", [{"r_path": 3}, {"r_persist": 1}, {"r_path": 3, "r_tol": 1e30},
+                                {"r_persist": 1, "r_tol": 1e30}, {"r_path": 3, "r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
                                 {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"f_form": 4}, {"f_form": 4, "f_tol": 1e30},
-                                {"r_nopad": 1}, {"_pair_table": 1},
-                                {"_pair_table": 1, "r_persist": 1}, {"_pair_table": 1, "r_ub": 1}, {"_pair_table": 1, "r_nopre": 1},
-                                {"r_prefetch": 1}, {"r_direct": 1}, {"r_direct": 1, "r_ub": 1},
+                                {"r_path": 3, "r_nopad": 1}, {"r_path": 3, "_pair_table": 1},
+                                {"_pair_table": 1, "r_persist": 1}, {"r_path": 3, "_pair_table": 1, "r_ub": 1},
+                                {"r_path": 3, "_pair_table": 1, "r_nopre": 1},
+                                {"r_path": 3, "r_prefetch": 1}, {"r_path": 3, "r_direct": 1}, {"r_path": 3, "r_direct": 1, "r_ub": 1},
+                                {"r_path": 3, "r_stagger": 1},
                                 {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
                               "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel",
                               "triple-f-kernel", "triple-f-kernel-exact", "no-pad",
                               "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
-                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient",
+                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient", "staggered",
                               "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
@@ -476,7 +478,7 @@ def test_gibbs_r_pass_on_two_streams(env, knobs, N, U, G, mode, ub):
     two-patient panels, U > 64) on two streams gives the oracle's chains, sweep after sweep (the fork / join keeps the
     f pass, the packing and the tally in order with both halves).
     """
-    knobs(r_streams=2, r_ub=ub)
+    knobs(r_streams=2, r_ub=ub, r_path=3)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 17 + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
