@@ -904,6 +904,14 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 #ifndef FCD_PIPE_PF_F
 #define FCD_PIPE_PF_F 2
 #endif
+// (diagnostic build only: six stamps inside row 8 of every block of the in-order scan, wave 0 -- profiles/trace_pipe.py)
+#ifdef FCD_ABLATE
+#define PIPE_ROW_USE(x) do { if (i == 8) asm volatile("" ::"v"(x)); } while (0)
+#define PIPE_ROW_STAMP(k) do { if (i == 8) { FCD_TRACE((16 + b) * 1024 + (int)blockIdx.x, k); } } while (0)
+#else
+#define PIPE_ROW_USE(x) do { } while (0)
+#define PIPE_ROW_STAMP(k) do { } while (0)
+#endif
 #ifndef PIPE_SCHED_BARRIER
 #define PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -1281,18 +1289,25 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
 #pragma unroll
         for (int i = 0; i < R_NB; ++i) {
             if (i < nb) {
+                PIPE_ROW_STAMP(0);
                 {
                     const int ie = i + PF_E - 1, jf = i + PF_F - 1;
                     const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
-                    fb[jf % PF_F] = fro[ulane];
-                    fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
-                    ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
+                    if (!FCD_ABL(2, 3)) {                         // (ablation 3: no f words; 4: no panel values either)
+                        fb[jf % PF_F] = fro[ulane];
+                        fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+                    }
+                    if (!FCD_ABL(2, 4)) ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
                 }
                 const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
                 // one byte per pair: (q << 2) | tt -- tile A against block b-1 (this wave's own redrawn bytes), tile B against
                 // the own block (redrawn below i, old above i; the record of (i, i) is zero)
                 const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
-                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
+                PIPE_ROW_USE(za.x ^ zb.x ^ za.y ^ zb.y);
+                PIPE_ROW_STAMP(1);
+                double v = FCD_ABL(2, 4) ? 1.0 : pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
+                PIPE_ROW_USE((uint32_t)__double2hiint(v));
+                PIPE_ROW_STAMP(2);
                 if (FCD_ABL(2, 2)) {                          // (ablation: no terms -- the wait for e stays)
                     fresh |= (v + (double)(za.x + zb.y) > 0.0 ? 1u : 0u) << i;
                     continue;
@@ -1314,11 +1329,15 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                     const double a1 = four(za, ra, 4);
                     PIPE_SCHED_BARRIER();
                     sa = a0 + a1;
+                    PIPE_ROW_USE((uint32_t)__double2hiint(sa));
+                    PIPE_ROW_STAMP(3);
                     const double b0 = four(zb, rb, 0);
                     PIPE_SCHED_BARRIER();
                     const double b1 = four(zb, rb, 4);
                     PIPE_SCHED_BARRIER();
                     sb = b0 + b1;
+                    PIPE_ROW_USE((uint32_t)__double2hiint(sb));
+                    PIPE_ROW_STAMP(4);
                 }
                 v = (v + sa) + sb;
                 if (__ballot(fabs(v) < a.tol) != 0ull)      // too close to call with the fast threshold in e_i: the exact one
@@ -1331,6 +1350,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 const int sh = 8 * ((i >> 1) & 3) + (i & 1);
                 if ((i >> 1) < 4) rcur.x = (rcur.x & ~(one << sh)) | (t << sh);
                 else rcur.y = (rcur.y & ~(one << sh)) | (t << sh);
+                PIPE_ROW_STAMP(5);
                 PIPE_SCHED_BARRIER();
             }
         }

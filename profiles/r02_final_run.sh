@@ -20,8 +20,10 @@ FCD_F_FORM=3 timeout -k 10 600 python3 bench.py --nreg 400 --subjects 500 --step
 timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_lds -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vb > $O/pmc_lds.log 2>&1; rc=$?; stop_if_killed $rc
 find $O/pmc_lds -name "*counter_collection.csv" -exec cp {} $O/pmc_lds_cfg3.csv \;
 python3 profiles/pmc_lds_summary.py $O/pmc_lds_cfg3.csv "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vb   (cfg3, final build of round 2)" > $O/r02_pmc_lds_cfg3.txt
-# the pipelined one-launch r pass (knob r_path=2) beside the default: same bench, 500 steps each; its strands and timeline
-FCD_R_PATH=2 timeout -k 10 300 python3 bench.py --steps 500 --warmup 10 --no-cpu-baseline --no-vb --no-corr > $O/r02_bench_cfg3_500steps_pipelined.json 2> $O/bench_500p.err; rc=$?; stop_if_killed $rc
+# the step-per-launch form of the r pass (knob r_path=3) beside the default (pipelined one-launch form): same bench, 500 steps
+FCD_R_PATH=3 timeout -k 10 300 python3 bench.py --steps 500 --warmup 10 --no-cpu-baseline --no-vb --no-corr > $O/r02_bench_cfg3_500steps_step_form.json 2> $O/bench_500p.err; rc=$?; stop_if_killed $rc
+FCD_R_PATH=3 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vb --no-corr > $O/r02_bench_cfg3_step_form.json 2>> $O/bench_500p.err; rc=$?; stop_if_killed $rc
+timeout -k 10 300 python3 profiles/fixed_cost.py > $O/r02_fixed_cost.txt 2>&1; rc=$?; stop_if_killed $rc
 FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so timeout -k 10 300 python3 profiles/ablate_pipe.py > $O/r02_ablate_pipe.txt 2>&1; rc=$?; stop_if_killed $rc
 FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so timeout -k 10 300 python3 profiles/trace_pipe.py > $O/r02_trace_pipe.txt 2>&1; rc=$?; stop_if_killed $rc
 FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so timeout -k 10 300 python3 profiles/ablate.py > $O/r02_ablate.txt 2>&1; rc=$?; stop_if_killed $rc

@@ -35,7 +35,7 @@ def main():
     for s in range(3):
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
-    nl = 16
+    nl = 32
     buf = torch.zeros((nl * 1024, 8), dtype=torch.int64, device="cuda")
     os.environ["FCD_TRACE_PTR"] = hex(buf.data_ptr())
     eng.r_step(100)
@@ -64,6 +64,15 @@ def main():
                     np.median(x[:, 5] - x[:, 3]) / 100, np.median(x[:, 1] - x[:, 5]) / 100,
                     np.median(x[:, 2] - x[:, 1]) / 100, np.median(x[:, 4] - x[:, 2]) / 100,
                     np.median(en), en.max()))
+    # inside row 8 of the in-order scan (wave 0 of every D workgroup): stamps 0 start, 1 f words there, 2 e there,
+    # 3 tile A summed, 4 tile B summed, 5 decided
+    for b in range(3, 10):
+        x = t[16 + b]
+        ok = x[:, 0] > 0
+        if ok.any():
+            d = np.diff(x[ok][:, :6], axis=1) / 100.0
+            print("block %d, row 8: f words %.2f  e %.2f  tile A %.2f  tile B %.2f  decision %.2f  (median us; whole row %.2f)" % (
+                (b,) + tuple(np.median(d, axis=0)) + (np.median((x[ok][:, 5] - x[ok][:, 0]) / 100.0),)))
     m = t[0, :, 0] > 0
     hw = t[0][m][:, 7].astype(np.int64)
     role = t[0][m][:, 6].astype(np.int64) & 255
