@@ -16,6 +16,7 @@ void fcd_abl_refresh(hipStream_t s) {
     if (const char *e = getenv("FCD_ABL_F")) v[0] = atoi(e);
     if (const char *e = getenv("FCD_ABL_PANEL")) v[1] = atoi(e);
     if (const char *e = getenv("FCD_ABL_DIAG")) v[2] = atoi(e);
+    if (const char *e = getenv("FCD_TRACE_ROW")) v[3] = atoi(e);       // stamps inside one row of the pipelined scan
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(fcd_abl_level), v, sizeof(v), 0, hipMemcpyHostToDevice, s);
 }
 #endif

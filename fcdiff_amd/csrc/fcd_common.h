@@ -272,7 +272,7 @@ static inline int fcd_geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G
 // Results are wrong whenever the level is non-zero.  In the product build FCD_ABL(x) folds to false.
 // ---------------------------------------------------------------------------------------------
 #ifdef FCD_ABLATE
-extern __device__ int fcd_abl_level[4];   // [0] f kernel, [1] panel, [2] diag
+extern __device__ int fcd_abl_level[4];   // [0] f kernel, [1] panel, [2] diag, [3] row stamps of the pipelined scan
 #define FCD_ABL(slot, lvl) (fcd_abl_level[slot] >= (lvl))
 void fcd_abl_refresh(hipStream_t s);
 // Timeline of the r step kernel: record (launch, workgroup) x 8 words of the 100 MHz clock, written by thread 0

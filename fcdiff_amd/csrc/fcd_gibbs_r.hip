@@ -904,10 +904,11 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 #ifndef FCD_PIPE_PF_F
 #define FCD_PIPE_PF_F 2
 #endif
-// (diagnostic build only: six stamps inside row 8 of every block of the in-order scan, wave 0 -- profiles/trace_pipe.py)
+// (diagnostic build only, FCD_TRACE_ROW=1: six stamps inside row 8 of every block of the in-order scan, wave 0 --
+// profiles/trace_pipe.py; each stamp costs about half a microsecond)
 #ifdef FCD_ABLATE
-#define PIPE_ROW_USE(x) do { if (i == 8) asm volatile("" ::"v"(x)); } while (0)
-#define PIPE_ROW_STAMP(k) do { if (i == 8) { FCD_TRACE((16 + b) * 1024 + (int)blockIdx.x, k); } } while (0)
+#define PIPE_ROW_USE(x) do { if (i == 8 && FCD_ABL(3, 1)) asm volatile("" ::"v"(x)); } while (0)
+#define PIPE_ROW_STAMP(k) do { if (i == 8 && FCD_ABL(3, 1)) { FCD_TRACE((16 + b) * 1024 + (int)blockIdx.x, k); } } while (0)
 #else
 #define PIPE_ROW_USE(x) do { } while (0)
 #define PIPE_ROW_STAMP(k) do { } while (0)
@@ -1293,11 +1294,9 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 {
                     const int ie = i + PF_E - 1, jf = i + PF_F - 1;
                     const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
-                    if (!FCD_ABL(2, 3)) {                         // (ablation 3: no f words; 4: no panel values either)
-                        fb[jf % PF_F] = fro[ulane];
-                        fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
-                    }
-                    if (!FCD_ABL(2, 4)) ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
+                    fb[jf % PF_F] = fro[ulane];
+                    fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+                    ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
                 }
                 const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
                 // one byte per pair: (q << 2) | tt -- tile A against block b-1 (this wave's own redrawn bytes), tile B against
@@ -1305,7 +1304,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
                 PIPE_ROW_USE(za.x ^ zb.x ^ za.y ^ zb.y);
                 PIPE_ROW_STAMP(1);
-                double v = FCD_ABL(2, 4) ? 1.0 : pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
+                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
                 PIPE_ROW_USE((uint32_t)__double2hiint(v));
                 PIPE_ROW_STAMP(2);
                 if (FCD_ABL(2, 2)) {                          // (ablation: no terms -- the wait for e stays)

@@ -69,7 +69,7 @@ def main():
     for b in range(3, 10):
         x = t[16 + b]
         ok = x[:, 0] > 0
-        if ok.any():
+        if ok.any():            # (only with FCD_TRACE_ROW=1; the stamps themselves cost ~0.5 us each)
             d = np.diff(x[ok][:, :6], axis=1) / 100.0
             print("block %d, row 8: f words %.2f  e %.2f  tile A %.2f  tile B %.2f  decision %.2f  (median us; whole row %.2f)" % (
                 (b,) + tuple(np.median(d, axis=0)) + (np.median((x[ok][:, 5] - x[ok][:, 0]) / 100.0),)))
