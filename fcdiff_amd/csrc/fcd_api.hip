@@ -161,6 +161,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_streams = (int)knob_env("FCD_R_STREAMS");
     ctx->knobs.r_prefetch = (int)knob_env("FCD_R_PREFETCH");
     ctx->knobs.r_stagger = (int)knob_env("FCD_R_STAGGER");
+    ctx->knobs.r_xcd = (int)knob_env("FCD_R_XCD");
     ctx->knobs.r_nopre = (int)knob_env("FCD_R_NOPRE");
     ctx->knobs.r_direct = (int)knob_env("FCD_R_DIRECT");
     ctx->side_stream = ctx->ev_fork = ctx->ev_join = nullptr;
@@ -258,6 +259,7 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_streams")) k.r_streams = (int)value;
     else if (!strcmp(name, "r_prefetch")) k.r_prefetch = (int)value;
     else if (!strcmp(name, "r_stagger")) k.r_stagger = (int)value;
+    else if (!strcmp(name, "r_xcd")) k.r_xcd = (int)value;
     else if (!strcmp(name, "r_nopre")) k.r_nopre = (int)value;
     else if (!strcmp(name, "r_direct")) k.r_direct = (int)value;
     else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");

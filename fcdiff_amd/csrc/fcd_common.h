@@ -28,6 +28,7 @@ struct fcd_knobs {
     int r_nopre;       // 1: ignore the pair-record table (build the records in LDS at every block step)
     int r_direct;      // 1: panel role builds its pair records straight from the table rows (no single rows in LDS)
     int r_prefetch;    // 1: panel workgroups touch the table rows of the next block step (L2 warm-up hint)
+    int r_xcd;         // 1: pipelined r pass deals contiguous pieces of its (chunk, row) list to the XCDs (a chunk's rows on one XCD)
     int r_stagger;     // > 0: the second panel workgroup of every CU starts r_stagger x 3.5 us late (launches of several rounds)
     int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form;

@@ -265,6 +265,7 @@ struct r_step_args {
     uint64_t seed;
     int prefetch;           // panel role: touch the next step's table rows (knob r_prefetch)
     int direct;             // panel role: build the pair records straight from the table rows, no single rows in LDS (knob r_direct)
+    int xcd;                // pipelined form: contiguous pieces of the (chunk, row) list per XCD (knob r_xcd)
     int stagger;            // step-per-launch form: the second workgroup of a CU starts this many x 3.5 us late (knob r_stagger)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
 };
@@ -1394,6 +1395,22 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_pipe_kernel(const r_step_ar
                 return;
             }
         }
+        if (a.xcd) {
+            // (knob r_xcd) Workgroups are dealt to the 8 XCDs round-robin by block index; give each XCD a CONTIGUOUS piece of
+            // the (chunk, row) list, so that the 16 rows of a chunk -- which all read that chunk's r bytes -- sit on one
+            // XCD (two at a piece boundary) and its L2 holds them once instead of eight times.  A heuristic about
+            // placement only: every (chunk, row) is still served exactly once.
+            auto upto = [](int n, int r) { return n <= 0 ? 0 : (n + 7 - r) >> 3; };            // block indices < n with residue r
+            auto panel_before = [&](int n, int r) {                                           // ... that are panel workgroups
+                int c = upto(n, r) - upto(a.nD < n ? a.nD : n, r);
+                if (a.npad) c -= upto(n < a.ncu + a.npad ? n : a.ncu + a.npad, r) - upto(n < a.ncu ? n : a.ncu, r);
+                return c;
+            };
+            const int x = blk & 7, end = a.nD + a.nP + a.npad;
+            int start = 0;
+            for (int y = 0; y < x; ++y) start += panel_before(end, y);
+            item = start + panel_before(blk, x);
+        }
         const int row = item % R_NB, uc = item / R_NB;
         for (int wg = 0; wg < a.nWG; ++wg) pipe_panel<UB>(a, row, uc, wg, smem, err);
     }
@@ -1942,6 +1959,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.prefetch = ctx->knobs.r_prefetch;
     a.direct = ctx->knobs.r_direct;
     a.stagger = ctx->knobs.r_stagger;
+    a.xcd = ctx->knobs.r_xcd;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);

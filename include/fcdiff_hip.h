@@ -85,6 +85,8 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_nopre"   1: ignore the pair-record table lMp (build the records in LDS at every block step)
  *   "r_direct"  1: panel records built straight from the table rows (rejected: slower; kept for the record)
  *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (no gain; kept for the record)
+ *   "r_stagger" k: step form, the second panel workgroup of every CU starts k x 3.5 us late; "r_xcd" 1: pipelined form,
+ *               contiguous pieces of the (chunk, row) list per XCD (both measured: no gain; kept for the record)
  *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form;
  *               4: records for triples of patients (U <= 72)

@@ -434,13 +434,14 @@ def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
                                 {"r_path": 3, "_pair_table": 1, "r_nopre": 1},
                                 {"r_path": 3, "r_prefetch": 1}, {"r_path": 3, "r_direct": 1}, {"r_path": 3, "r_direct": 1, "r_ub": 1},
                                 {"r_path": 3, "r_stagger": 1},
-                                {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1}],
+                                {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1},
+                                {"r_path": 2, "r_xcd": 1}],
                          ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
                               "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel",
                               "triple-f-kernel", "triple-f-kernel-exact", "no-pad",
                               "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
                               "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient", "staggered",
-                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
+                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad", "pipelined-xcd-pieces"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
