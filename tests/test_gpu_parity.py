@@ -588,6 +588,43 @@ def test_gibbs_f_pass_triple_records(env, knobs, N, U, G):
         nptest.assert_array_equal(r_g, r_o)
 
 
+def _random_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        N = int(rng.choice([2, 3, 5, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 90, 120]))
+        U = int(rng.choice([1, 2, 3, 4, 5, 8, 11, 16, 23, 37]))
+        G = int(rng.choice([64, 70, 128, 200, 512, 1024, 1100, 2048]))
+        mode = "reference" if (rng.rand() < 0.3 and N > 2) else "symmetric"
+        out.append((N, U, G, mode))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,U,G,mode", _random_shapes(14, 20261004))
+def test_gibbs_default_path_random_shapes(env, N, U, G, mode):
+    """
+    The default path (pair-record f kernel, pipelined one-launch r pass wherever it fits, fused tally) on shapes drawn at
+    random from the awkward ones -- two regions, exactly one / just over one / several blocks of 16 regions, one patient,
+    odd patient counts, partial chain words, two groups of chain words, both edge-id modes -- against the C oracle,
+    three sweeps through fcd_gibbs_run.
+    """
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=7 * N + U)
+    seed = 1000 + N + U
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=128, seed=seed, edge_index=mode, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 128)
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    eng.run(0, 3, mstep_every=0)
+    for s in range(3):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 128)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 128)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
 @pytest.mark.gpu
 def test_gibbs_sweeps_driver_equals_separate_passes(env):
     """
