@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""
+The two roles of the pipelined r pass (default form) timed ALONE at cfg3 (diagnostic; `make -C fcdiff_amd/csrc ABLATE=1`):
+
+    FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so python profiles/ablate_pipe2.py
+
+FCD_TRACE_ROW=2 switches every hand-over wait off (the in-order role takes whatever the panel buffers hold, the panel
+role does not look for marks), FCD_ABL_PANEL=7 / FCD_ABL_DIAG=7 leave the panel / in-order workgroups empty.
+Results of ablated runs are wrong by design -- only the times matter.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fcdiff_amd  # noqa: E402
+from fcdiff_amd.gibbs import GibbsEngine  # noqa: E402
+
+
+def main():
+    (Nreg, H, U, G) = (200, 50, 50, 1024)
+    if len(sys.argv) > 3:
+        (Nreg, U, G) = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+        H = U
+    model = fcdiff_amd.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = model.sample_fast(Nreg, H, U, seed=0)
+    fit = fcdiff_amd.fit.UnsharedRegionFit()
+    fit.model, fit.b, fit.bt = model, b, bt
+    fit._init_lps(Nreg, H, U)
+    fit._update_lps()
+    eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, seed=1, ctx=fit._context())
+    eng.set_hyper(model.gamma, model.pi2())
+    eng.init(float(model.pi))
+    for s in range(3):
+        eng.sweeps(s, 1)
+    torch.cuda.synchronize()
+    cases = [("full", {}),
+             ("no hand-over waits", {"FCD_TRACE_ROW": "2"}),
+             ("in-order role alone, no waits", {"FCD_TRACE_ROW": "2", "FCD_ABL_PANEL": "7"}),
+             ("in-order role alone, no waits, no terms", {"FCD_TRACE_ROW": "2", "FCD_ABL_PANEL": "7", "FCD_ABL_DIAG": "2"}),
+             ("in-order role alone, no waits, no terms, no feed loads in the scan", {"FCD_TRACE_ROW": "2", "FCD_ABL_PANEL": "7", "FCD_ABL_DIAG": "3"}),
+             ("panel role alone, no waits", {"FCD_TRACE_ROW": "2", "FCD_ABL_DIAG": "7"}),
+             ("panel role alone, no waits, no terms", {"FCD_TRACE_ROW": "2", "FCD_ABL_DIAG": "7", "FCD_ABL_PANEL": "2"}),
+             ("both empty (packing launch + empty grid)", {"FCD_ABL_DIAG": "7", "FCD_ABL_PANEL": "7"})]
+    res = {name: [] for (name, _) in cases}
+    for rnd in range(5):
+        for (name, env) in cases:
+            for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG", "FCD_TRACE_ROW"):
+                os.environ.pop(k, None)
+            for (k, v) in env.items():
+                os.environ[k] = v
+            eng.r_step(100)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                eng.r_step(101 + i)
+            e1.record()
+            torch.cuda.synchronize()
+            res[name].append(e0.elapsed_time(e1) / 5 * 1e3)
+    for (name, _) in cases:
+        print("%-70s %8.1f us (min %8.1f)   [pass incl. the packing launch]" % (name, float(np.median(res[name])), float(np.min(res[name]))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+// How many cycles of its SIMD does a wave64 vector instruction take?  (The sweep kernels are bound by vector-instruction
+// issue: this decides what an address or a sum may cost.)  8 waves per SIMD, every CU; cycles from s_memtime in the kernel,
+// so the clock the chip holds does not matter.
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d at %d\n", e, __LINE__); return 1; } } while (0)
+
+#define REP8(x) x x x x x x x x
+#define BODY(NAME, ASM)                                                                                   \
+    __global__ __launch_bounds__(512) void NAME(uint64_t *out, int iters) {                               \
+        uint32_t a = threadIdx.x, b = threadIdx.x * 3 + 1, c = 7, d = 9;                                   \
+        double x = threadIdx.x, y = 1.5;                                                                  \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                 \
+        for (int it = 0; it < iters; ++it) { REP8(REP8(asm volatile(ASM : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(x), "+v"(y));)) } \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                 \
+        if (threadIdx.x % 64 == 0) out[blockIdx.x * 8 + threadIdx.x / 64] = t1 - t0;                     \
+        if (a + b + c + d + (uint32_t)x + (uint32_t)y == 0x12345) out[0] = 0;                             \
+    }
+// each ASM body = 2 independent instructions
+BODY(k_and, "v_and_b32 %0, %1, %0\n v_and_b32 %2, %3, %2")
+BODY(k_lshr, "v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %2, 5, %2")
+BODY(k_andor, "v_and_or_b32 %0, %1, 24, %0\n v_and_or_b32 %2, %3, 24, %2")
+BODY(k_andlit, "v_and_b32 %0, 0x1e0, %0\n v_and_b32 %2, 0x1f8, %2")
+BODY(k_addu, "v_add_u32 %0, %1, %0\n v_add_u32 %2, %3, %2")
+BODY(k_lshladd, "v_lshl_add_u32 %0, %1, 3, %0\n v_lshl_add_u32 %2, %3, 3, %2")
+BODY(k_bfe, "v_bfe_u32 %0, %1, 8, 6\n v_bfe_u32 %2, %3, 16, 6")
+BODY(k_madu24, "v_mad_u32_u24 %0, %1, 8, %0\n v_mad_u32_u24 %2, %3, 8, %2")
+BODY(k_perm, "v_perm_b32 %0, %1, %0, %3\n v_perm_b32 %2, %3, %2, %1")
+BODY(k_fma32, "v_fma_f32 %0, %1, %0, %1\n v_fma_f32 %2, %3, %2, %3")
+BODY(k_add64, "v_add_f64 %4, %4, %5\n v_add_f64 %5, %5, %4")
+BODY(k_mulhi, "v_mul_hi_u32 %0, %1, %0\n v_mul_hi_u32 %2, %3, %2")
+BODY(k_mullo, "v_mul_lo_u32 %0, %1, %0\n v_mul_lo_u32 %2, %3, %2")
+BODY(k_cndmask, "v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc")
+BODY(k_sdwa, "v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_or_b32_sdwa %2, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2")
+BODY(k_pkadd, "v_pk_add_f32 %4, %4, %5\n v_pk_add_f32 %5, %5, %4")
+
+int main() {
+    hipDeviceProp_t p;
+    CHECK(hipGetDeviceProperties(&p, 0));
+    const int cus = p.multiProcessorCount;
+    uint64_t *out;
+    CHECK(hipMalloc(&out, (size_t)cus * 8 * 4 * 8));
+    struct { const char *name; void (*fn)(uint64_t *, int); } ks[] = {
+        {"v_and_b32", k_and}, {"v_lshrrev_b32", k_lshr}, {"v_and_or_b32 (inline const)", k_andor}, {"v_and_b32 (literal)", k_andlit},
+        {"v_add_u32", k_addu}, {"v_lshl_add_u32", k_lshladd}, {"v_bfe_u32", k_bfe}, {"v_mad_u32_u24", k_madu24}, {"v_perm_b32", k_perm},
+        {"v_fma_f32", k_fma32}, {"v_add_f64", k_add64}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_lo_u32", k_mullo}, {"v_cndmask_b32", k_cndmask},
+        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}};
+    const int iters = 2000;
+    uint64_t *h = (uint64_t *)malloc((size_t)cus * 4 * 8 * 8);
+    for (auto &k : ks) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k.fn, dim3(cus * 4), dim3(512), 0, 0, out, iters);       // 4 blocks x 8 waves = 32 waves per CU = 8 per SIMD
+            CHECK(hipDeviceSynchronize());
+        }
+        CHECK(hipMemcpy(h, out, (size_t)cus * 4 * 8 * 8, hipMemcpyDeviceToHost));
+        double s = 0;
+        for (int i = 0; i < cus * 4 * 8; ++i) s += (double)h[i];
+        s /= cus * 4 * 8;
+        // each wave issued iters * 64 * 2 instructions; 8 waves share a SIMD
+        printf("%-32s %6.2f cycles of the SIMD per wave-instruction (8 waves per SIMD)\n", k.name, s / ((double)iters * 128 * 8));
+    }
+    return 0;
+}
