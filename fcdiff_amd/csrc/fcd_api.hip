@@ -47,19 +47,6 @@ int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes) {
     return FCD_OK;
 }
 
-int fcd_pipe_state_reserve(fcd_ctx *ctx, size_t bytes) {
-    if (bytes <= ctx->pipe_state_bytes) return FCD_OK;
-    FCD_HIP_TRY(hipDeviceSynchronize());
-    if (ctx->pipe_state) FCD_HIP_TRY(hipFree(ctx->pipe_state));
-    ctx->pipe_state = nullptr;
-    ctx->pipe_state_bytes = 0;
-    ctx->pipe_key[0] = 0;                  // whatever was there is gone: initialise before the next pipelined pass
-    FCD_HIP_TRY(hipMalloc(&ctx->pipe_state, bytes));
-    ctx->pipe_state_bytes = bytes;
-    ctx->n_alloc += 1;
-    return FCD_OK;
-}
-
 void fcd_sweep_ws_bytes(const fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t GW, size_t *ws_bytes, size_t *fsq_bytes) {
     const size_t f = fcd_f_pass_ws_bytes(Nreg, U, GW), r = fcd_r_pass_ws_bytes(Nreg, U, GW, ctx->knobs.r_path);
     *ws_bytes = f > r ? f : r;
@@ -162,12 +149,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->msg[0] = 0;
     ctx->n_alloc = 0;
     for (int i = 0; i < FCD_KA_N; ++i) ctx->lds_attr[i] = 0;
-    for (int i = 0; i < 3; ++i) ctx->pipe_occ[i] = ctx->pipe2_occ[i] = -1;
-    ctx->pipe_state = nullptr;
-    ctx->pipe_state_bytes = 0;
-    ctx->pipe_key[0] = ctx->pipe_key[1] = ctx->pipe_key[2] = 0;
-    ctx->pipe_gen = 0;
-    ctx->r_form_last = ctx->r_groups_last = 0;
+    for (int i = 0; i < 3; ++i) ctx->pipe_occ[i] = -1;
     // the only place the environment is read: defaults of the knobs (fcd_ctx_set_knob changes them later)
     ctx->knobs.r_path = (int)knob_env("FCD_R_PATH");
     ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");
@@ -182,7 +164,6 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_xcd = (int)knob_env("FCD_R_XCD");
     ctx->knobs.r_nopre = (int)knob_env("FCD_R_NOPRE");
     ctx->knobs.r_direct = (int)knob_env("FCD_R_DIRECT");
-    ctx->knobs.r_dbg = (int)knob_env("FCD_R_DBG");
     ctx->side_stream = ctx->ev_fork = ctx->ev_join = nullptr;
     {
         hipStream_t st = nullptr;
@@ -239,7 +220,6 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     if (ctx->fsq) (void)hipFree(ctx->fsq);
-    if (ctx->pipe_state) (void)hipFree(ctx->pipe_state);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->ev_fork) (void)hipEventDestroy((hipEvent_t)ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy((hipEvent_t)ctx->ev_join);
@@ -263,8 +243,6 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G) {
     if (sweep > need) need = sweep;
     int rc = fcd_ws_reserve(ctx, need);
     if (rc) return rc;
-    rc = fcd_pipe_state_reserve(ctx, fcd_r_pipe_state_bytes(Nreg, U, GW));
-    if (rc) return rc;
     return fsq ? fcd_fsq_reserve(ctx, fsq) : FCD_OK;
 }
 
@@ -284,7 +262,6 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_xcd")) k.r_xcd = (int)value;
     else if (!strcmp(name, "r_nopre")) k.r_nopre = (int)value;
     else if (!strcmp(name, "r_direct")) k.r_direct = (int)value;
-    else if (!strcmp(name, "r_dbg")) k.r_dbg = (int)value;
     else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");
     return FCD_OK;
 }
@@ -294,9 +271,6 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out) {
     if (!strcmp(name, "n_alloc")) *out = ctx->n_alloc;
     else if (!strcmp(name, "ws_bytes")) *out = (int64_t)ctx->ws_bytes;
     else if (!strcmp(name, "fsq_bytes")) *out = (int64_t)ctx->fsq_bytes;
-    else if (!strcmp(name, "r_form_last")) *out = ctx->r_form_last;
-    else if (!strcmp(name, "r_groups_last")) *out = ctx->r_groups_last;
-    else if (!strcmp(name, "dev_err")) *out = ctx->dev_err ? (int64_t)*ctx->dev_err : 0;
     else return FCD_ERR_ARG;
     return FCD_OK;
 }

@@ -31,7 +31,6 @@ struct fcd_knobs {
     int r_xcd;         // 1: pipelined r pass deals contiguous pieces of its (chunk, row) list to the XCDs (a chunk's rows on one XCD)
     int r_stagger;     // > 0: the second panel workgroup of every CU starts r_stagger x 3.5 us late (launches of several rounds)
     int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
-    int r_dbg;         // DIAGNOSTIC (wrong results when set): bits switch parts of the pipelined r pass off, see r_pipe2_args.dbg
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form;
                        // 4: triple records (U <= 72)
 };
@@ -39,7 +38,7 @@ struct fcd_knobs {
 // kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
 enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
        FCD_KA_F_TRI = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_STEP = FCD_KA_F_TRI + 6, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_R_PIPE = FCD_KA_R_PASS + 4,
-       FCD_KA_R_PIPE2 = FCD_KA_R_PIPE + 4, FCD_KA_N = FCD_KA_R_PIPE2 + 4 };
+       FCD_KA_N = FCD_KA_R_PIPE + 4 };
 
 struct fcd_ctx {
     int device;
@@ -52,16 +51,6 @@ struct fcd_ctx {
     int pipe_occ[3];               // pipelined r pass: workgroups per CU of the three kernel variants (-1: not asked yet) ...
     size_t pipe_occ_shmem[3];      // ... for this much dynamic LDS
     int pipe_occ_threads[3];       // ... and this many threads
-    int pipe2_occ[3];              // the same for gibbs_r_pipe2_kernel (the default pipelined form)
-    size_t pipe2_occ_shmem[3];
-    int pipe2_occ_threads[3];
-    // hand-over state of the pipelined r pass that lives ACROSS passes (tagged panel values, generation-valued marks):
-    void *pipe_state;              // Pbuf[2] | marks, made by fcd_pipe_state_reserve
-    size_t pipe_state_bytes;
-    int64_t pipe_key[3];           // (Nreg, U, GW) the state was initialised for; [0] = 0: not initialised
-    uint32_t pipe_gen;             // pipelined passes run on that state so far
-    int r_form_last;               // which form the last blocked r pass ran in: 1 step-per-launch, 2 pipelined (fcd_ctx_stat)
-    int r_groups_last;             // ... and in how many patient groups (pipelined form)
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *side_stream; // hipStream_t + two events for the two-stream r pass (knob r_streams), made by fcd_ctx_create
@@ -102,9 +91,6 @@ int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes);
 void fcd_sweep_ws_bytes(const fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t GW, size_t *ws_bytes, size_t *fsq_bytes);
 size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW);     // fcd_gibbs.hip
 size_t fcd_r_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW, int r_path);   // fcd_gibbs_r.hip
-// persistent hand-over state of the pipelined r pass (0 bytes where that form cannot run); reserve = grow only
-size_t fcd_r_pipe_state_bytes(int64_t Nreg, int64_t U, int64_t GW);            // fcd_gibbs_r.hip
-int fcd_pipe_state_reserve(fcd_ctx *ctx, size_t bytes);
 size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW);      // fcd_gibbs.hip: 0 when the fused driver keeps no square copy
 // raise a kernel's dynamic-LDS limit if this size was not set before (no HIP call otherwise)
 static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t shmem) {

@@ -118,31 +118,12 @@ __device__ __forceinline__ uint32_t pair_off6(uint2 z, int p) {
     return s == 0 ? (w << 3) & 0x1F8u : (w >> (s - 3)) & 0x1F8u;
 }
 
-// nibble word of a pair word (8 pairs x 4 bits: q of pairs 0-3 in the low nibbles of the four bytes, q of pairs 4-7 in
-// the high ones) <-> byte form (q << 2 per byte): what the in-order role of the pipelined pass loads (f_D2)
-__device__ __forceinline__ uint32_t p2_to_nibbles(uint2 bytes) {
-    return ((bytes.x >> 2) & 0x0F0F0F0Fu) | (((bytes.y >> 2) & 0x0F0F0F0Fu) << 4);
-}
-__device__ __forceinline__ uint2 p2_from_nibbles(uint32_t nw) { return make_uint2((nw & 0x0F0F0F0Fu) << 2, (nw >> 2) & 0x3C3C3C3Cu); }
-
-// r pair words as nibbles (tt = r_m + 2 r_m+1 of pairs 0-3 in the low nibbles of the four bytes, of pairs 4-7 in the high ones)
-__device__ __forceinline__ uint32_t p2_r_to_nibbles(uint2 bytes) { return (bytes.x & 0x03030303u) | ((bytes.y & 0x03030303u) << 4); }
-__device__ __forceinline__ uint2 p2_r_from_nibbles(uint32_t nw) { return make_uint2(nw & 0x03030303u, (nw >> 4) & 0x03030303u); }
-// what the packing launch makes for the pipelined pass (all nullable): nibble words, FOUR blocks of 16 regions per 16 bytes
-//   f_D2[w][n / 2][lane]      {fa(2p), fb(2p), fa(2p+1), fb(2p+1)}: row n against the block before / its own block (in-order role)
-//   f_N[w][n][b / 4][lane]    uint4, word b % 4 = nibble word of block b                                   (panel role)
-//   r_N[w][u][b / 4][lane]    uint4, likewise for the r bits; the in-order role overwrites block b's word once it is redrawn
-struct p2_pack_out {
-    uint32_t *f_D2, *f_N, *r_N;
-    int NB4;
-};
-
 // (w, n, b) wave-uniform: all index arithmetic is scalar, 32-bit (C * 64 fits an int, checked by the host)
 // SQ: f_state is the square copy [w][n][m][lane] (rows contiguous in m) instead of the edge-major state
 template <bool SQ>
 __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32, int mode,
                                             uint2 *__restrict__ f_S, int w, int n, int b, int lane,
-                                            uint8_t *__restrict__ lds_wave, const p2_pack_out &po) {
+                                            uint8_t *__restrict__ lds_wave) {
     const uint8_t *__restrict__ fw = SQ ? f_state + ((int64_t)w * Nreg + n) * Nreg * 64 : f_state + (int64_t)w * C32 * 64;
     const int tn = (n * (n - 1)) >> 1;
     const uint32_t sh = 8u * (uint32_t)(lane & 3);
@@ -191,11 +172,7 @@ __device__ __forceinline__ void pack_f_item(const uint8_t *__restrict__ f_state,
             const uint32_t k1 = (m1 < Nreg && m1 != n) ? k[x][2 * p + 1] : 0u;
             v[p >> 2] |= ((k0 * 3u + k1) << 2) << (8 * (p & 3));
         }
-        if (f_S) f_S[(((int64_t)w * Nreg + n) * NBLK + b + x) * 64 + lane] = make_uint2(v[0], v[1]);
-        const uint32_t nw = p2_to_nibbles(make_uint2(v[0], v[1]));
-        if (po.f_N) po.f_N[((((int64_t)w * Nreg + n) * po.NB4 + ((b + x) >> 2)) * 64 + lane) * 4 + ((b + x) & 3)] = nw;
-        if (po.f_D2 && (b + x == (n >> 4) || b + x == (n >> 4) - 1))
-            po.f_D2[((((int64_t)w * (NBLK * (R_NB / 2)) + (n >> 1)) * 64 + lane) << 2) + ((n & 1) << 1) + (b + x == (n >> 4) ? 1 : 0)] = nw;
+        f_S[(((int64_t)w * Nreg + n) * NBLK + b + x) * 64 + lane] = make_uint2(v[0], v[1]);
     }
 }
 
@@ -209,7 +186,7 @@ struct r_pipe_init {
 constexpr unsigned long long R_SENT = 0x7FF8DEADBEEF0001ull;      // "no panel value here yet" (a NaN no sum can produce)
 __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NBLK,
                                             uint2 *__restrict__ r_S, int w, int u, int b, int lane,
-                                            const r_pipe_init &pipe, const p2_pack_out &po) {
+                                            const r_pipe_init &pipe) {
     if (pipe.marks) {
         if (lane == 0) pipe.marks[((int64_t)w * U + u) * NBLK + b] = 0u;
         if (b < 2) {                                     // (a single block never uses the second buffer)
@@ -226,9 +203,7 @@ __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits,
         v |= (m < Nreg ? (uint32_t)((word >> lane) & 1ull) : 0u) << j;
     }
     const int64_t o = (((int64_t)w * U + u) * NBLK + b) * 64 + lane;
-    const uint2 sp = spread2(v);
-    if (r_S) r_S[o] = sp;
-    if (po.r_N) po.r_N[((((int64_t)w * U + u) * po.NB4 + (b >> 2)) * 64 + lane) * 4 + (b & 3)] = p2_r_to_nibbles(sp);
+    r_S[o] = spread2(v);
 }
 
 // grid (ceil(NBLK / (4 FB)), Nreg + U, GW): one wave per (w, n, FB blocks from b) resp. (w, u, FB blocks), no index
@@ -238,17 +213,17 @@ template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
                                                      int mode, uint2 *__restrict__ f_S, const uint64_t *__restrict__ r_bits,
                                                      int U, uint2 *__restrict__ r_S,
-                                                     const r_pipe_init pipe, const p2_pack_out po) {
+                                                     const r_pipe_init pipe) {
     constexpr int FB = SQ ? 2 : 1;
     const int b = FB * __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
     const int y = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
     __shared__ __attribute__((aligned(16))) uint8_t turn[4][FB * R_NB * 64];      // one kilobyte per wave and block (square-copy form)
-    if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane, turn[threadIdx.x >> 6], po);
+    if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane, turn[threadIdx.x >> 6]);
     else {
 #pragma unroll
         for (int x = 0; x < FB; ++x)
-            if (b + x < NBLK) pack_r_item(r_bits, Nreg, U, NBLK, r_S, (int)blockIdx.z, y - Nreg, b + x, lane, pipe, po);
+            if (b + x < NBLK) pack_r_item(r_bits, Nreg, U, NBLK, r_S, (int)blockIdx.z, y - Nreg, b + x, lane, pipe);
     }
 }
 
@@ -998,11 +973,6 @@ __device__ __attribute__((noinline)) double pipe_exact_corr(uint32_t idx, uint32
 }
 
 // Panel workgroup of the pipelined form: all steps of (row, uc) for the group wg of chain words.
-#ifndef FCD_OLD_PIPE_SYNC
-#define PIPE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
-#define PIPE_LDS_BARRIER() __syncthreads()
-#endif
 template <int UB>
 __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc, int wg, double *smem, volatile unsigned *err) {
     constexpr int P_GRP = UB == 1 ? P_GRP_1 : P_GRP_2;
@@ -1069,7 +1039,7 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
                 store_rows(it0, v);
             }
         }
-        PIPE_LDS_BARRIER();                                   // rows in place; every wave is done with the previous records
+        __syncthreads();                                   // rows in place; every wave is done with the previous records
         {
             const int q = threadIdx.x % 9, step = blockDim.x / 9;
             const int k = q / 3, k2 = q - 3 * k;
@@ -1085,7 +1055,7 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
                 }
             }
         }
-        PIPE_LDS_BARRIER();                                   // records in place; the scratch is free
+        __syncthreads();                                   // records in place; the scratch is free
         FCD_TRACE(trec, 1);
         // the NEXT step's rows: requested now, parked in the scratch after the thresholds are made (one turn of the
         // piece loop covers every shape whose rows fit the LDS at all: total <= 2 * blockDim pieces ... else a second turn)
@@ -1242,7 +1212,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
         }
 #pragma unroll
         for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<true>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
-        PIPE_LDS_BARRIER();                                   // every wave is done with the previous block's records
+        __syncthreads();                                   // every wave is done with the previous block's records
         FCD_TRACE(trec, 3);
         {
             const double2 *rowbase = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6) + B0 * 3;
@@ -1272,7 +1242,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 }
             }
         }
-        PIPE_LDS_BARRIER();
+        __syncthreads();
         FCD_TRACE_VAL(trec, 5, wall_clock64());
         {
             const int q = threadIdx.x % 9, step = blockDim.x / 9;
@@ -1296,7 +1266,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                     four(sA, rec, lo, hi);
                     put(rec, lo, hi);
                 }
-            PIPE_LDS_BARRIER();                                  // single A is free: tile 1 may overwrite it
+            __syncthreads();                                  // single A is free: tile 1 may overwrite it
             const int safe = compact ? D_SAFE : D_RECS_T;
             if (on)
                 for (int rec = r0; rec < safe; rec += step) {
@@ -1309,11 +1279,11 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 const bool mine = on && rec < D_RECS_T;
                 double2 lo = make_double2(0.0, 0.0), hi = lo;
                 if (mine) four(sB, rec, lo, hi);
-                PIPE_LDS_BARRIER();
+                __syncthreads();
                 if (mine) put(D_RECS_T + rec, lo, hi);
             }
         }
-        PIPE_LDS_BARRIER();
+        __syncthreads();
         FCD_TRACE(trec, 1);
         if (!live) continue;
         __builtin_amdgcn_s_setprio(3);
@@ -1407,8 +1377,6 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
         __builtin_amdgcn_s_setprio(0);
     }
 }
-
-#include "fcd_gibbs_rp.inc"
 
 // grid = nD + (empty workgroups beside them) + 16 nUC: workgroup (u) / (row, uc); groups of chain words one after the
 // other.  The host launches it only if every workgroup is resident at once.
@@ -1803,35 +1771,9 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
     return FCD_OK;
 }
 
-// pipelined form (gibbs_r_pipe2_kernel): *slots = workgroups the device holds at once (asked for once per shape)
-template <int UB, int WPE>
-int launch_pipe2(fcd_ctx *ctx, const r_pipe2_args &a, size_t shmem, int threads, int *slots, bool launch, hipStream_t s) {
-    const void *fn = reinterpret_cast<const void *>(&gibbs_r_pipe2_kernel<UB, WPE>);
-    const int slot = UB == 4 ? 2 : UB - 1;
-    {
-        int rc = fcd_lds_attr(ctx, FCD_KA_R_PIPE2 + slot, fn, shmem);
-        if (rc) return rc;
-    }
-    if (ctx->pipe2_occ[slot] < 0 || ctx->pipe2_occ_shmem[slot] != shmem || ctx->pipe2_occ_threads[slot] != threads) {
-        int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, shmem);
-        if (e != hipSuccess) return (int)e;
-        ctx->pipe2_occ[slot] = per_cu;
-        ctx->pipe2_occ_shmem[slot] = shmem;
-        ctx->pipe2_occ_threads[slot] = threads;
-    }
-    *slots = ctx->pipe2_occ[slot] * ctx->num_cu;
-    if (!launch) return FCD_OK;
-    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
-    hipLaunchKernelGGL((gibbs_r_pipe2_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), shmem, s, a, ctx->dev_err);
-    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
-    FCD_LAUNCH_CHECK();
-    return FCD_OK;
-}
-
-// workspace of the blocked path: P[2] | f_S | r_S | r_Sn | flags | f_D2   (one formula for reserve and launch)
+// workspace of the blocked path: P[2] | f_S | r_S | r_Sn | flags   (one formula for reserve and launch)
 struct r_ws_layout {
-    size_t t_bytes, f_bytes, s_bytes, flag_words, d2_bytes, fn_bytes, rn_bytes, total;
+    size_t t_bytes, f_bytes, s_bytes, flag_words, total;
 };
 static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
     r_ws_layout L;
@@ -1842,11 +1784,7 @@ static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
     const int64_t nWGs = (GW + 15) / 16;
     // one-launch form: counters of (at most U) chunks + its error word; pipelined form: one mark per (word, patient, block)
     L.flag_words = (size_t)2 * nWGs * U * NBLK + 1 + (size_t)GW * U * NBLK;
-    const int64_t NB4 = (NBLK + 3) / 4;
-    L.d2_bytes = (size_t)GW * NBLK * (R_NB / 2) * 64 * sizeof(uint4);      // nibble words of the pipelined pass: in-order role ...
-    L.fn_bytes = (size_t)GW * Nreg * NB4 * 64 * sizeof(uint4);             // ... panel role, f
-    L.rn_bytes = (size_t)GW * U * NB4 * 64 * sizeof(uint4);                // ... r (updated in place by the in-order role)
-    L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512 + L.d2_bytes + L.fn_bytes + L.rn_bytes;
+    L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
     return L;
 }
 static size_t r_ws_seq(int64_t Nreg, int64_t U, int64_t GW) {
@@ -1855,13 +1793,6 @@ static size_t r_ws_seq(int64_t Nreg, int64_t U, int64_t GW) {
 }
 
 }  // namespace
-
-size_t fcd_r_pipe_state_bytes(int64_t Nreg, int64_t U, int64_t GW) {
-    const size_t per_u_need = (size_t)((Nreg + R_NB - 1) / R_NB) * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
-    if (per_u_need > 156 * 1024 || Nreg + U > 65535) return 0;          // generic kernel: no hand-over
-    const int64_t NBLK = (Nreg + R_NB - 1) / R_NB;
-    return (size_t)2 * GW * U * R_NB * 64 * sizeof(double) + (size_t)GW * U * NBLK * sizeof(uint32_t) + 256;
-}
 
 size_t fcd_r_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW, int r_path) {
     const size_t per_u_need = (size_t)((Nreg + R_NB - 1) / R_NB) * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
@@ -2038,68 +1969,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     bool pipe = false;
     r_pipe_init pinit;
     pinit.marks = nullptr; pinit.P[0] = pinit.P[1] = nullptr;
-    // ---- the default: pipelined form with tagged hand-overs, patients in as many groups as the device needs ----
-    bool pipe2 = false;
-    r_pipe2_args a2;
-    const int threads2 = 64 * a.wpb;
-    p2_pack_out po;
-    po.f_D2 = po.f_N = po.r_N = nullptr; po.NB4 = 0;
     if ((ctx->knobs.r_path == 0 || ctx->knobs.r_path == 2) && ctx->dev_err && !persist && ctx->knobs.r_streams != 2) {
-        memset(&a2, 0, sizeof(a2));
-        int slots = 0;
-        shmem += 512;                                // room to start the panel tile on a 512-byte boundary
-        if (shmem > 160 * 1024) shmem = 160 * 1024;
-        if (ub == 4) rc = launch_pipe2<4, 4>(ctx, a2, shmem, threads2, &slots, false, s);
-        else if (ub == 2) rc = launch_pipe2<2, 8>(ctx, a2, shmem, threads2, &slots, false, s);
-        else rc = launch_pipe2<1, 8>(ctx, a2, shmem, threads2, &slots, false, s);
-        if (rc) return rc;
-        // Ug patients per group: Ug in-order + 16 Ug / ub panel workgroups resident at once, a few slots to spare
-        const int64_t room = (int64_t)slots - 4;
-        int64_t cap = room > 0 ? room * ub / (ub + R_NB) : 0;
-        cap = cap / ub * ub;
-        const size_t st_bytes = fcd_r_pipe_state_bytes(Nreg, U, g.GW);
-        if (cap >= ub && st_bytes > 0 && (int64_t)g.GW * U * NBLK * (R_NB / 2) < INT32_MAX / 256) {
-            int64_t nPG = (U + cap - 1) / cap;
-            int64_t Ug = ((U + nPG - 1) / nPG + ub - 1) / ub * ub;           // balanced groups, whole chunks
-            nPG = (U + Ug - 1) / Ug;
-            rc = fcd_pipe_state_reserve(ctx, st_bytes);
-            if (rc) return rc;
-            char *ps = (char *)ctx->pipe_state;
-            const size_t pb = (size_t)g.GW * U * R_NB * 64 * sizeof(double);
-            if (ctx->pipe_key[0] != Nreg || ctx->pipe_key[1] != U || ctx->pipe_key[2] != g.GW) {
-                hipLaunchKernelGGL(p2_state_init_kernel, dim3((unsigned)(ctx->num_cu * 4)), dim3(256), 0, s, (unsigned long long *)ps,
-                                   2 * pb / sizeof(double), (uint32_t *)(ps + 2 * pb), (size_t)g.GW * U * NBLK);
-                FCD_LAUNCH_CHECK();
-                ctx->pipe_key[0] = Nreg; ctx->pipe_key[1] = U; ctx->pipe_key[2] = g.GW;
-                ctx->pipe_gen = 0;
-            }
-            pipe2 = true;
-            {
-                char *d2p = wsp + L.flag_words * sizeof(uint32_t);           // behind the flags, 16-byte aligned (the layout's 512 spare bytes)
-                d2p += (16 - ((uintptr_t)d2p & 15)) & 15;
-                po.f_D2 = (uint32_t *)d2p;
-                po.f_N = (uint32_t *)(d2p + L.d2_bytes);
-                po.r_N = (uint32_t *)(d2p + L.d2_bytes + L.fn_bytes);
-                po.NB4 = (NBLK + 3) / 4;
-            }
-            a2.lMd = lMd; a2.hyper = hyper; a2.f_D2 = (const uint4 *)po.f_D2; a2.f_N = (const uint4 *)po.f_N; a2.r_N = (uint4 *)po.r_N;
-            a2.NB4 = po.NB4;
-            a2.r_bits = r_bits;
-            a2.Pbuf[0] = (double *)ps; a2.Pbuf[1] = (double *)(ps + pb);
-            a2.marks = (uint32_t *)(ps + 2 * pb);
-            a2.Nreg = (int)Nreg; a2.U = (int)U; a2.NBLK = NBLK; a2.GW = g.GW;
-            a2.wpb = a.wpb; a2.nWG = a.nWG;
-            a2.Ug = (int)Ug; a2.nPG = (int)nPG;
-            a2.nD = (int)(Ug < U ? Ug : U);
-            a2.nP = R_NB * (int)((a2.nD + ub - 1) / ub);
-            a2.ncu = ctx->num_cu;
-            a2.npad = (!ctx->knobs.r_nopad && a2.nD <= a2.ncu && a2.nD + a2.nP > a2.ncu) ? a2.nD : 0;
-            a2.chain0 = (uint32_t)chain0; a2.sweep = (uint32_t)sweep; a2.seed = seed; a2.gen = ctx->pipe_gen;
-            a2.tol = a.tol;
-            a2.dbg = ctx->knobs.r_dbg;
-        }
-    }
-    if (!pipe2 && (ctx->knobs.r_path == 4) && ctx->dev_err && !persist && ctx->knobs.r_streams != 2) {
         a.nD = (int)U;
         a.nP = R_NB * nUC;
         a.npad = (!ctx->knobs.r_nopad && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
@@ -2120,26 +1990,14 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         dim3 pgrid((unsigned)(((NBLK + fb - 1) / fb + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
         fcd_prof_begin(ctx, FCD_PROF_PACK, s);
         if (fsq)
-            hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode,
-                               pipe2 ? nullptr : f_S, r_bits, (int)U, pipe2 ? nullptr : r_S, pinit, po);
+            hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
+                               (int)U, r_S, pinit);
         else
-            hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode,
-                               pipe2 ? nullptr : f_S, r_bits, (int)U, pipe2 ? nullptr : r_S, pinit, po);
+            hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
+                               r_bits, (int)U, r_S, pinit);
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
-    if (pipe2) {
-        int slots = 0;
-        if (ub == 4) rc = launch_pipe2<4, 4>(ctx, a2, shmem, threads2, &slots, true, s);
-        else if (ub == 2) rc = launch_pipe2<2, 8>(ctx, a2, shmem, threads2, &slots, true, s);
-        else rc = launch_pipe2<1, 8>(ctx, a2, shmem, threads2, &slots, true, s);
-        if (rc) return rc;
-        ctx->pipe_gen += 1;
-        ctx->r_form_last = 2;
-        ctx->r_groups_last = a2.nPG;
-        return FCD_OK;
-    }
-    ctx->r_form_last = pipe ? 3 : 1;
     if (pipe) {
         a.flags = pinit.marks;
         if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, true, s);
