@@ -38,6 +38,8 @@ SIGNATURES = {
     "fcd_ctx_reserve": (_int, [_p, _i64, _i64, _i64]),
     "fcd_ctx_set_knob": (_int, [_p, C.c_char_p, _dbl]),
     "fcd_ctx_stat": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "fcd_ctx_check": (_int, [_p]),
+    "fcd_ctx_clear_error": (_int, [_p]),
     "fcd_prof_enable": (_int, [_p, _int]),
     "fcd_prof_collect": (_int, [_p, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     "fcd_N_to_C": (_i64, [_i64]),
@@ -165,6 +167,17 @@ class Context(object):
         v = _i64()
         self.call("fcd_ctx_stat", name.encode(), C.byref(v))
         return v.value
+
+    def check_device(self):
+        """
+        Raise FcdiffHipError if a kernel of this context gave up a device-side wait (pipelined r pass).  The word is
+        written by the device, so call this after something that synchronises with the sweeps (a .cpu() read, a
+        torch.cuda.synchronize()): GibbsEngine does after every host read of chain state or counts.
+        """
+        self.call("fcd_ctx_check")
+
+    def clear_error(self):
+        self.call("fcd_ctx_clear_error")
 
     PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "pack_f_kernel": 3}
 

@@ -164,6 +164,9 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_xcd = (int)knob_env("FCD_R_XCD");
     ctx->knobs.r_nopre = (int)knob_env("FCD_R_NOPRE");
     ctx->knobs.r_direct = (int)knob_env("FCD_R_DIRECT");
+    ctx->knobs.r_poll_limit = (int)knob_env("FCD_R_POLL_LIMIT");
+    ctx->knobs.r_withhold = (int)knob_env("FCD_R_WITHHOLD");
+    ctx->r_form_last = 0;
     ctx->side_stream = ctx->ev_fork = ctx->ev_join = nullptr;
     {
         hipStream_t st = nullptr;
@@ -262,7 +265,22 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_xcd")) k.r_xcd = (int)value;
     else if (!strcmp(name, "r_nopre")) k.r_nopre = (int)value;
     else if (!strcmp(name, "r_direct")) k.r_direct = (int)value;
+    else if (!strcmp(name, "r_poll_limit")) k.r_poll_limit = (int)value;
+    else if (!strcmp(name, "r_withhold")) k.r_withhold = (int)value;
     else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");
+    return FCD_OK;
+}
+
+int fcd_ctx_check(fcd_ctx *ctx) {
+    if (!ctx) return FCD_ERR_ARG;
+    if (ctx->dev_err && *ctx->dev_err)
+        return fcd_fail(ctx, FCD_ERR_DEVICE, "a device-side wait of the pipelined r pass was abandoned: the chain state is unusable");
+    return FCD_OK;
+}
+
+int fcd_ctx_clear_error(fcd_ctx *ctx) {
+    if (!ctx) return FCD_ERR_ARG;
+    if (ctx->dev_err) *ctx->dev_err = 0u;
     return FCD_OK;
 }
 
@@ -271,6 +289,8 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out) {
     if (!strcmp(name, "n_alloc")) *out = ctx->n_alloc;
     else if (!strcmp(name, "ws_bytes")) *out = (int64_t)ctx->ws_bytes;
     else if (!strcmp(name, "fsq_bytes")) *out = (int64_t)ctx->fsq_bytes;
+    else if (!strcmp(name, "r_form_last")) *out = ctx->r_form_last;
+    else if (!strcmp(name, "dev_err")) *out = ctx->dev_err ? (int64_t)*ctx->dev_err : 0;
     else return FCD_ERR_ARG;
     return FCD_OK;
 }

@@ -31,6 +31,8 @@ struct fcd_knobs {
     int r_xcd;         // 1: pipelined r pass deals contiguous pieces of its (chunk, row) list to the XCDs (a chunk's rows on one XCD)
     int r_stagger;     // > 0: the second panel workgroup of every CU starts r_stagger x 3.5 us late (launches of several rounds)
     int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
+    int r_poll_limit;  // TEST HOOK: > 0 bounds every device-side poll of the pipelined r pass by this many polls (default 2^20, ~1 s)
+    int r_withhold;    // TEST HOOK: 1 = the in-order role of the pipelined r pass never sets its marks (a panel wave then gives up)
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form;
                        // 4: triple records (U <= 72)
 };
@@ -51,6 +53,7 @@ struct fcd_ctx {
     int pipe_occ[3];               // pipelined r pass: workgroups per CU of the three kernel variants (-1: not asked yet) ...
     size_t pipe_occ_shmem[3];      // ... for this much dynamic LDS
     int pipe_occ_threads[3];       // ... and this many threads
+    int r_form_last;               // form of the last blocked r pass: 1 step-per-launch, 2 pipelined, 3 one-launch with counters (fcd_ctx_stat)
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *side_stream; // hipStream_t + two events for the two-stream r pass (knob r_streams), made by fcd_ctx_create

@@ -268,6 +268,8 @@ struct r_step_args {
     int xcd;                // pipelined form: contiguous pieces of the (chunk, row) list per XCD (knob r_xcd)
     int stagger;            // step-per-launch form: the second workgroup of a CU starts this many x 3.5 us late (knob r_stagger)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
+    int poll_limit;         // pipelined form: polls before a wait is given up (R_POLL_LIMIT; smaller only through the test hook)
+    int withhold;           // TEST HOOK (knob r_withhold): the in-order role never sets its marks
 };
 
 // ---- cross-workgroup hand-over of the one-launch form ----
@@ -917,20 +919,21 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
 #ifndef PIPE_SCHED_BARRIER
 #define PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
-constexpr int R_POLL_LIMIT = 1 << 16;                              // x (sleep + one trip to the memory side)
+constexpr int R_PIPE_SLOT_MARGIN = 8;                              // free workgroup slots the pipelined form insists on
+constexpr int R_POLL_LIMIT = 1 << 20;                              // x (sleep + one trip to the memory side): about a second
 
 // err: the context's pinned host word.  ok: false once this wave has given up (it then never waits again).
 __device__ __forceinline__ void pipe_give_up(volatile unsigned *err, bool &ok) {
     __hip_atomic_store(const_cast<unsigned *>(err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     ok = false;
 }
-__device__ __forceinline__ void pipe_poll_mark(const uint32_t *mark, volatile unsigned *err, bool &ok) {
+__device__ __forceinline__ void pipe_poll_mark(const uint32_t *mark, int limit, volatile unsigned *err, bool &ok) {
     int spins = 0;
     while (ok) {
         const uint32_t v = __hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (wave-uniform address)
         if (__builtin_amdgcn_readfirstlane((int)v) != 0) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > R_POLL_LIMIT) pipe_give_up(err, ok);
+        if (++spins > limit) pipe_give_up(err, ok);
         else if ((spins & 255) == 0 &&
                  __hip_atomic_load(const_cast<unsigned *>(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
             ok = false;
@@ -940,13 +943,13 @@ __device__ __forceinline__ void pipe_poll_mark(const uint32_t *mark, volatile un
 // The panel value at p is not there yet (some lane still reads the sentinel): poll until it is, or give up.  Out of line
 // on purpose -- a loop with a load in it, inlined into the 16-row scan, makes the compiler wait for EVERY load in flight
 // (the next rows' requests included) at each row, i.e. one trip to the memory side per row.
-__device__ __attribute__((noinline)) double pipe_wait_e(const double *p, volatile unsigned *err) {
+__device__ __attribute__((noinline)) double pipe_wait_e(const double *p, int limit, volatile unsigned *err) {
     double e;
     int spins = 0;
     bool ok = true;
     do {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > R_POLL_LIMIT) pipe_give_up(err, ok);
+        if (++spins > limit) pipe_give_up(err, ok);
         else if ((spins & 255) == 0 &&
                  __hip_atomic_load(const_cast<unsigned *>(err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
             ok = false;
@@ -954,10 +957,10 @@ __device__ __attribute__((noinline)) double pipe_wait_e(const double *p, volatil
     } while (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull);
     return e;                                   // (still the sentinel in some lane: the wait was given up)
 }
-__device__ __forceinline__ double pipe_poll_e(const double *p, double first, volatile unsigned *err, bool &ok) {
+__device__ __forceinline__ double pipe_poll_e(const double *p, double first, int limit, volatile unsigned *err, bool &ok) {
     double e = first;
     if (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) {
-        e = pipe_wait_e(p, err);
+        e = pipe_wait_e(p, limit, err);
         if (__ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) ok = false;
     }
     return e;
@@ -1110,7 +1113,7 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
             if (!polled && jlast >= NV - 1) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (u < nu) pipe_poll_mark(a.flags + ((int64_t)wl * U + u0 + u) * NBLK + (st - 2), err, ok);
+                    if (u < nu) pipe_poll_mark(a.flags + ((int64_t)wl * U + u0 + u) * NBLK + (st - 2), a.poll_limit, err, ok);
                 polled = true;
                 FCD_TRACE(trec, 3);
             }
@@ -1305,7 +1308,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
                 const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
                 PIPE_ROW_USE(za.x ^ zb.x ^ za.y ^ zb.y);
                 PIPE_ROW_STAMP(1);
-                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], err, ok);
+                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], a.poll_limit, err, ok);
                 PIPE_ROW_USE((uint32_t)__double2hiint(v));
                 PIPE_ROW_STAMP(2);
                 if (FCD_ABL(2, 2)) {                          // (ablation: no terms -- the wait for e stays)
@@ -1372,7 +1375,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
             __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // bytes, sentinels and r_bits are out before the block is announced
-        if (lane == 0) __hip_atomic_store(a.flags + wu * NBLK + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !a.withhold) __hip_atomic_store(a.flags + wu * NBLK + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         FCD_TRACE(trec, 4);
         __builtin_amdgcn_s_setprio(0);
     }
@@ -1762,7 +1765,9 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
         ctx->pipe_occ_shmem[slot] = shmem;
         ctx->pipe_occ_threads[slot] = threads;
     }
-    *fits = (int64_t)ctx->pipe_occ[slot] * ctx->num_cu >= (int64_t)a.nD + a.nP;
+    // every workgroup resident at once, with a few slots to spare (the occupancy query knows nothing of other kernels
+    // on the device; a workgroup that starts late only makes the others wait -- every poll is bounded)
+    *fits = (int64_t)ctx->pipe_occ[slot] * ctx->num_cu >= (int64_t)a.nD + a.nP + R_PIPE_SLOT_MARGIN;
     if (!*fits || !launch) return FCD_OK;
     fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
     hipLaunchKernelGGL((gibbs_r_pipe_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), shmem, s, a, ctx->dev_err);
@@ -1961,6 +1966,8 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.stagger = ctx->knobs.r_stagger;
     a.xcd = ctx->knobs.r_xcd;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
+    a.poll_limit = ctx->knobs.r_poll_limit > 0 ? ctx->knobs.r_poll_limit : R_POLL_LIMIT;
+    a.withhold = ctx->knobs.r_withhold;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
     const int persist = ctx->knobs.r_persist;     // EXPERIMENTAL one-launch form (slower)
@@ -1998,6 +2005,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
+    ctx->r_form_last = pipe ? 2 : (persist ? 3 : 1);
     if (pipe) {
         a.flags = pinit.marks;
         if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, true, s);

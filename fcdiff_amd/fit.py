@@ -465,8 +465,8 @@ class UnsharedRegionFit(object):
                 if want_e:
                     self.energy.append(-float(lj.mean()))
                 if want_t:
-                    traces.append(lj.cpu().numpy())
-                    traces_r.append(e.r_sums().cpu().numpy())
+                    traces.append(e.host(lj))
+                    traces_r.append(e.host(e.r_sums()))
             if self.update_theta_sub and self.theta_sub_every and (i + 1) % self.theta_sub_every == 0 and i + 1 < self.n_sweeps:
                 # Monte-Carlo EM for (eta, epsilon): pooled counts of (f_c, mixture case) over all chains of all ranks
                 W = e.pair_counts()
@@ -490,6 +490,9 @@ class UnsharedRegionFit(object):
         cnt = t.cat([eng.cnt_f.reshape(-1).to(t.int64), eng.cnt_r.reshape(-1).to(t.int64),
                      t.tensor([eng.n_accumulated * eng.G], dtype=t.int64, device=eng.cnt_f.device)])
         cnt = allreduce_counts(cnt).cpu().numpy().astype(np.float64)
+        # (that read waited for every sweep: a pipelined r pass that gave up a device-side wait has raised the
+        # context's error word by now -- no marginals, pi or gamma from such a state)
+        eng.ctx.check_device()
         C = util.N_to_C(N)
         total = max(cnt[-1], 1.0)
         with np.errstate(divide="ignore"):

@@ -110,7 +110,14 @@ class GibbsEngine(object):
 
     def hyper_values(self):
         h = self.hyper.cpu().numpy()
+        self.ctx.check_device()
         return np.exp(h[0:3]), float(np.exp(h[4]))
+
+    def host(self, t):
+        """Device tensor -> NumPy array; raises if a sweep before it abandoned a device-side wait (fcd_ctx_check)."""
+        a = t.cpu().numpy()
+        self.ctx.check_device()
+        return a
 
     # ---- state ----
     def init(self, pi):
@@ -123,7 +130,9 @@ class GibbsEngine(object):
         r = t.empty((self.G, self.Nreg, self.U), dtype=t.uint8, device=self.f_state.device)
         self.ctx.call("fcd_gibbs_export_state", _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U,
                       self.G, _lib.dptr(f), _lib.dptr(r), _lib.stream_ptr())
-        return f.cpu().numpy(), r.cpu().numpy()
+        (fh, rh) = (f.cpu().numpy(), r.cpu().numpy())
+        self.ctx.check_device()          # (the copies above waited for every sweep before them)
+        return fh, rh
 
     def import_state(self, f, r):
         t = self.torch
@@ -236,7 +245,7 @@ def _world_size(group=None):
 
 
 def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_theta=True, group=None,
-               on_sweep=None, mstep_lag=0):
+               on_sweep=None, mstep_lag=0, force_collective=False):
     """
     The sampler loop shared by UnsharedRegionFit(method='gibbs') and bench.py.
 
@@ -249,12 +258,16 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
         The schedule -- and with it every chain's path -- is the same for any number of ranks, one rank included.
     `engine` is anything with run/mstep (the HIP engine here; the CPU tests pass an oracle-backed stand-in to
     exercise the multi-process logic under gloo).
+    force_collective=True takes the several-rank path -- counts, all-reduce, fcd_gibbs_mstep between calls -- also in a
+    process group of ONE rank (bench.py --force-pg, tests/test_dist_nccl.py: RCCL initialised and used on a one-GPU box;
+    the chains are those of the plain loop, bit for bit).
     """
     import torch.distributed as dist
     world = _world_size(group)
+    collective = world > 1 or (bool(force_collective) and dist.is_available() and dist.is_initialized())
     k = int(mstep_every) if (update_theta and mstep_every and mstep_every > 0) else 0
     acc_from = sweep0 + burn_in
-    if world == 1 and on_sweep is None and not mstep_lag:
+    if not collective and on_sweep is None and not mstep_lag:
         engine.run(sweep0, n_sweeps, mstep_every=k, accumulate_from=acc_from)
         return
     pending = None       # (counts clone, work handle or None): the M-step that waits for its turn (mstep_lag)
@@ -273,7 +286,7 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
             c = min(c, k - (i % k))
         end = i + c
         do_m = bool(k and end % k == 0)
-        local = do_m and world == 1 and not mstep_lag
+        local = do_m and not collective and not mstep_lag
         counts = engine.run(sweep0 + i, c, mstep_every=(c if local else 0), accumulate_from=acc_from,
                             want_counts=do_m and not local)
         if mstep_lag and pending is not None and do_m:      # one M-step PERIOD later, whatever the chunking
@@ -282,10 +295,12 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
         if do_m and not local:
             if mstep_lag:
                 cl = counts.clone()
-                work = dist.all_reduce(cl, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
+                work = dist.all_reduce(cl, op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None
                 pending = (cl, work)
             else:
-                engine.mstep(allreduce_counts(counts, group))
+                if collective:
+                    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+                engine.mstep(counts)
         if on_sweep is not None:
             on_sweep(i, engine)
         i = end

@@ -90,10 +90,21 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form;
  *               4: records for triples of patients (U <= 72)
+ *   "r_poll_limit", "r_withhold"  TEST HOOKS of the pipelined r pass: bound every device-side poll by this many polls /
+ *               the in-order role never announces a block (a panel wave then gives its wait up, fcd_ctx_check reports it)
  * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
 int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value);
-/* Counters of the context: "n_alloc" device allocations made so far, "ws_bytes", "fsq_bytes". */
+/* Counters of the context: "n_alloc" device allocations made so far, "ws_bytes", "fsq_bytes"; "r_form_last" = the form
+ * the last blocked r pass ran in (1 one launch per block step, 2 pipelined one-launch form, 3 one-launch form with
+ * counters); "dev_err" = the error word of the pipelined r pass as the host sees it now (see fcd_ctx_check). */
 int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out);
+/* FCD_ERR_DEVICE if a kernel of this context has abandoned a device-side wait (pipelined r pass: every poll of a mark or
+ * of a panel value is bounded, ~1 s), else FCD_OK.  The word is written by the device: call this AFTER the stream has been
+ * synchronised (or after any device-to-host read that follows the sweeps on that stream) -- the sampler entry points
+ * themselves only see a give-up of an EARLIER call.  Once set, the chain state is unusable; fcd_ctx_clear_error resets
+ * the word after the caller has re-initialised its chains. */
+int fcd_ctx_check(fcd_ctx *ctx);
+int fcd_ctx_clear_error(fcd_ctx *ctx);
 
 /* Optional timing of the library's main kernels with HIP events recorded on the launch stream, each pair
  * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r block step (or one-launch pass), 3 r pack.

@@ -16,7 +16,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir):
+def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir, with_group=True, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -25,7 +25,8 @@ def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    if with_group:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
         import fcdiff_amd
         from fcdiff_amd.gibbs import GibbsEngine, run_chains, shard_chains
@@ -40,15 +41,18 @@ def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir)
         eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], N, U, n_local, chain0=chain0, seed=seed, ctx=fit._context())
         eng.set_hyper(m.gamma, m.pi2())
         eng.init(0.2)
-        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag)
+        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=force)
         torch.cuda.synchronize()
         (f, r) = eng.export_state()
         cnt = eng.cnt_r.to(torch.int64).clone()
-        dist.all_reduce(cnt)
+        if with_group:
+            dist.all_reduce(cnt)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=f, r=r, hyper=eng.hyper.cpu().numpy(), chain0=chain0,
-                 cnt_r=cnt.cpu().numpy(), world=dist.get_world_size())
+                 cnt_r=cnt.cpu().numpy(), world=dist.get_world_size() if with_group else 0,
+                 r_form=eng.ctx.stat("r_form_last"))
     finally:
-        dist.destroy_process_group()
+        if with_group:
+            dist.destroy_process_group()
 
 
 def _free_port():
@@ -80,3 +84,30 @@ def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag):
     for p in parts:
         np.testing.assert_array_equal(p["hyper"], ref["hyper"])       # the same pooled (pi, gamma) on every rank
         np.testing.assert_array_equal(p["cnt_r"], ref["cnt_r"])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (1, 1), (2, 1)])
+def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag):
+    """
+    RCCL on the one GPU of the build box: a process group of ONE rank (backend nccl, initialised before anything touches
+    the GPU), and the several-rank loop forced on it -- counts, all-reduce (blocking, or asynchronous on the collective's
+    stream under the lagged schedule), work.wait(), fcd_gibbs_mstep -- beside the default pipelined r pass.  The chains,
+    the hyper-parameters and the marginal counters must equal those of the same schedule without any process group.
+    """
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    (total, n_sweeps, seed) = (192, 6, 31)
+    plain = tmp_path / "plain"
+    group = tmp_path / "group"
+    plain.mkdir()
+    group.mkdir()
+    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(plain), False, False), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(group), True, True), nprocs=1, join=True)
+    a = np.load(os.path.join(str(plain), "rank0.npz"))
+    b = np.load(os.path.join(str(group), "rank0.npz"))
+    assert int(b["world"]) == 1 and int(b["r_form"]) == 2          # (the pipelined form ran beside the collective)
+    for k in ("f", "r", "hyper", "cnt_r"):
+        np.testing.assert_array_equal(a[k], b[k])

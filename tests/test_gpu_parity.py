@@ -524,7 +524,111 @@ def test_gibbs_r_pass_pipelined(env, knobs, N, U, G, mode, ub):
     f_g, r_g = eng.export_state()
     nptest.assert_array_equal(f_g[:Go], f_o)
     nptest.assert_array_equal(r_g[:Go], r_o)
-    eng.sweeps(n_sw, 1)          # (a call after the pass: it would report a wait that was given up)
+    assert env.ctx.stat("r_form_last") == 2          # the pipelined kernel itself ran (not its fallback) ...
+    assert env.ctx.stat("dev_err") == 0              # ... and no wait was given up (export_state checked it too)
+
+
+@pytest.mark.gpu
+def test_gibbs_r_pass_falls_back_where_the_grid_does_not_fit(env):
+    """A grid larger than the device holds at once (cfg5-like: 400 + 16 x 400 workgroups) runs one launch per block step."""
+    (N, U, G) = (33, 400, 64)
+    (m, S_B, lM) = tables_for(env, N, 2, U, seed=N + U)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=0, seed=3, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, 3, 0)
+    eng.run(0, 1, mstep_every=0)
+    env.CO.gibbs_f_step(f_o, r_o, S_B, lM, np.log(m.gamma), 3, 0, 0)
+    env.CO.gibbs_r_step(f_o, r_o, lM, np.log(m.pi2()), 3, 0, env.lib.EDGE_MODES["symmetric"], 0)
+    f_g, r_g = eng.export_state()
+    assert env.ctx.stat("r_form_last") == 1
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+
+
+@pytest.mark.gpu
+def test_gibbs_pipelined_give_up_is_reported(env):
+    """
+    A device-side wait that is abandoned must not go unnoticed: with the test hooks r_withhold (the
+    in-order role never announces a block) and r_poll_limit (64 polls instead of ~1 s) a panel wave gives its wait up; the
+    error word of the context is raised, GibbsEngine refuses to hand out the state, the fit raises instead of returning
+    marginals, and every later sampler call on the context returns FCD_ERR_DEVICE until the error is cleared.
+    """
+    ctx = env.lib.Context()
+    ctx.set_knob("r_withhold", 1)
+    ctx.set_knob("r_poll_limit", 64)
+    (N, U, G) = (40, 6, 128)
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=0, seed=5, ctx=ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    eng.run(0, 2, mstep_every=0)                     # (queued: nothing has looked at the error word yet)
+    assert ctx.stat("r_form_last") == 2
+    with pytest.raises(env.lib.FcdiffHipError):
+        eng.export_state()
+    assert ctx.stat("dev_err") != 0
+    with pytest.raises(env.lib.FcdiffHipError):
+        eng.sweeps(2, 1)
+    # the fit: no marginals from such a state
+    fit = env.pkg.fit.UnsharedRegionFit()
+    fit._ctx = ctx
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, 3, U, seed=N + U)
+    fit.model, fit.b, fit.bt = m, b, bt
+    fit.method, fit.n_chains, fit.n_sweeps, fit.burn_in = "gibbs", 128, 3, 1
+    ctx.clear_error()
+    with pytest.raises(env.lib.FcdiffHipError):
+        fit.run()
+    # cleared and without the hooks the context works again
+    ctx.clear_error()
+    ctx.set_knob("r_withhold", 0)
+    ctx.set_knob("r_poll_limit", 0)
+    eng.init(0.3)
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, 5, 0)
+    eng.run(0, 1, mstep_every=0)
+    env.CO.gibbs_f_step(f_o, r_o, S_B, lM, np.log(m.gamma), 5, 0, 0)
+    env.CO.gibbs_r_step(f_o, r_o, lM, np.log(m.pi2()), 5, 0, env.lib.EDGE_MODES["symmetric"], 0)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(r_g, r_o)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gibbs_pipelined_pass_beside_a_foreign_kernel(env):
+    """
+    The pipelined r pass needs all its workgroups resident at once; the host checks that against an EMPTY device.  Here
+    another stream keeps the device busy with large matrix products (tens of milliseconds, every CU) while cfg3-sized
+    sweeps are queued: workgroups of the pass that find no slot start late, the others wait for them (bounded polls,
+    ~1 s) -- the chains must still be the oracle's and no wait may be given up.
+    """
+    t = env.torch
+    (N, U, G) = (200, 50, 1024)
+    (m, S_B, lM) = tables_for(env, N, 2, U, seed=11)
+    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=0, seed=9, ctx=env.ctx)
+    eng.set_hyper(m.gamma, m.pi2())
+    eng.init(0.3)
+    Go = 64
+    f_o, r_o = env.CO.gibbs_init(Go, N, U, 0.3, 9, 0)
+    side = t.cuda.Stream()
+    a = t.randn((6144, 6144), device="cuda")
+    b = t.randn((6144, 6144), device="cuda")
+    t.cuda.synchronize()
+    n_sw = 3
+    with t.cuda.stream(side):
+        for _ in range(12):
+            a = (a @ b) * 1e-3
+    eng.run(0, n_sw, mstep_every=0)                  # queued while the products run
+    with t.cuda.stream(side):
+        for _ in range(4):
+            a = (a @ b) * 1e-3
+    t.cuda.synchronize()
+    assert env.ctx.stat("r_form_last") == 2 and env.ctx.stat("dev_err") == 0
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    for s in range(n_sw):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, 9, s, 0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, 9, s, env.lib.EDGE_MODES["symmetric"], 0)
+    f_g, r_g = eng.export_state()
+    nptest.assert_array_equal(f_g[:Go], f_o)
+    nptest.assert_array_equal(r_g[:Go], r_o)
 
 
 @pytest.mark.gpu
