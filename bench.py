@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--mstep-lag", default="auto", choices=["auto", "0", "1"],
                     help="1: the M-step of sweep s is applied after sweep s+1, its all-reduce overlaps that sweep "
                          "(auto: 1 with several ranks, 0 with one)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="one rank only: initialise an RCCL process group of ONE rank anyway and run the several-rank loop "
+                         "(counts -> all-reduce -> fcd_gibbs_mstep, lagged schedule) on it: what an 8-GPU run does, on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vb", action="store_true", help="skip the variational-iteration comparison")
     ap.add_argument("--no-corr", action="store_true", help="skip the time-series front-end (K_corr)")
@@ -79,11 +82,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    ranks_seen = dist.get_world_size() if world > 1 else 1
-    lag = (1 if world > 1 else 0) if args.mstep_lag == "auto" else int(args.mstep_lag)
+        if world == 1:                         # (--force-pg without a launcher: a group of this one process)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if use_pg else 1
+    lag = (1 if use_pg else 0) if args.mstep_lag == "auto" else int(args.mstep_lag)
 
     import fcdiff_amd
     from fcdiff_amd.gibbs import GibbsEngine, run_chains
@@ -131,30 +142,36 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- timed region: W warm-up steps, then exactly K steps of the sampler loop ----
     s_w = args.settle                                                     # first warm-up sweep
     if args.settle > 0:
-        run_chains(eng, args.settle, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
-    run_chains(eng, args.warmup, sweep0=s_w, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
+        run_chains(eng, args.settle, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
+    run_chains(eng, args.warmup, sweep0=s_w, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
     fence()
     n_alloc0 = ctx.stat("n_alloc")
     t0 = time.perf_counter()
-    run_chains(eng, args.steps, sweep0=s_w + args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag)
+    run_chains(eng, args.steps, sweep0=s_w + args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
     fence()
     elapsed = time.perf_counter() - t0
     allocs_in_timed_region = ctx.stat("n_alloc") - n_alloc0
-    if world > 1:
+    ctx.check_device()                        # (a pipelined r pass that gave a wait up would have raised the error word by now)
+    r_form = {1: "one launch per block step", 2: "pipelined one-launch form", 3: "one-launch form with counters"}.get(ctx.stat("r_form_last"), "generic")
+    rank_ms = [elapsed / args.steps * 1e3]
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(tt) for _ in range(ranks_seen)]
+        dist.all_gather(gathered, tt)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in gathered]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- the collective, on its own: the 8-word all-reduce of the pooled counts ----
     allreduce_us = None
-    if world > 1:
+    if use_pg:
         cts = eng.counts.clone()
         for _ in range(5):
             dist.all_reduce(cts)
@@ -211,18 +228,28 @@ def main():
         dom_ms = kern[dom]["avg_launch_ms"]
         dom_bytes = per_launch_bytes[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        for tname in ("r02_pmc_traffic_%s.json" % cfg_key, "r01_pmc_traffic.json" if cfg_key == "cfg3" else ""):
-            tpath = os.path.join(ROOT, "profiles", tname)                 # HBM bytes per launch from the PMC passes
-            if tname and os.path.exists(tpath):
+        # HBM traffic of that kernel: NOT measured in this run (PMC passes cannot run beside the timed region) -- read from
+        # the summary of two rocprofv3 --pmc passes of this same command committed under profiles/ (pmc_traffic.py)
+        traffic = traffic_raw = traffic_src = None
+        for tname in ("r03_pmc_traffic_%s.json" % cfg_key, "r02_pmc_traffic_%s.json" % cfg_key):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                    rec = json.load(open(tpath)).get(dom, {})
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_raw = (rec.get("FETCH_SIZE_KiB_per_launch", 0.0) + rec.get("WRITE_SIZE_KiB_per_launch", 0.0)) * 1024.0
+                    traffic_src = "profiles/" + tname
                 except Exception:
                     traffic = None
                 if traffic is not None:
                     break
         roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src, "traffic_raw_counters": traffic_raw,
+                "traffic_note": "from an earlier profiled run of the same command, not from this run; 'traffic' = 2 x FETCH_SIZE + "
+                                "WRITE_SIZE (the guide's gfx950 correction, calibrated for 16-byte-per-lane streams; this kernel's "
+                                "per-lane loads are 8 bytes wide, for which the factor is not calibrated: the truth lies between "
+                                "'traffic_raw_counters' = FETCH_SIZE + WRITE_SIZE and 'traffic')",
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                 "launches_timed": kern[dom]["launches"],
                 "note": "dominant kernel by total time; HIP event pair around every launch (fcd_prof_*) in a second "
@@ -263,6 +290,8 @@ def main():
                                "(pi,gamma) M-step every %d sweep(s), fixed tables" % (cfg_name, Nreg, C, H, U, G, args.mstep_every),
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
                    "mstep_lag": lag, "ranks_seen": ranks_seen, "allreduce_us": allreduce_us,
+                   "process_group": ("nccl, %d rank(s)%s" % (ranks_seen, ", forced" if (args.force_pg and world == 1) else "")) if use_pg else None,
+                   "rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms), "r_pass_form": r_form,
                    "settle_sweeps": args.settle,     # untimed, before the W warm-up steps (burn-in; device steady state)
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},
         "roofline": roof,
@@ -336,7 +365,7 @@ def main():
                                          "(oracle/fcdiff_oracle.c, OpenMP over chains), %.1f s" % (n_c, n_sw, cfg_key, t_c)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -20,7 +20,7 @@ FCD_ERR_DEVICE = -5
 EDGE_REFERENCE = 0
 EDGE_SYMMETRIC = 1
 EDGE_MODES = {"reference": EDGE_REFERENCE, "symmetric": EDGE_SYMMETRIC}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -63,15 +63,13 @@ SIGNATURES = {
     "fcd_gibbs_edge_tables": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "fcd_gibbs_f_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _p]),
     "fcd_gibbs_region_tables": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
-    "fcd_gibbs_pair_table_bytes": (_int, [_i64, _i64, C.POINTER(C.c_size_t)]),
-    "fcd_gibbs_region_pair_tables": (_int, [_p, _p, _i64, _i64, _p, _p]),
-    "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
-    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
+    "fcd_gibbs_r_step": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _int, _p]),
+    "fcd_gibbs_sweeps": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _p, _p]),
     "fcd_gibbs_stats": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "fcd_gibbs_mstep": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "fcd_gibbs_accumulate": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "fcd_gibbs_tally": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p]),
-    "fcd_gibbs_run": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _i64, _i64, _p, _p,
+    "fcd_gibbs_run": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _u64, _i64, _i64, _int, _i64, _i64, _p, _p,
                             _p, _p]),
     "fcd_gibbs_logjoint": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "fcd_gibbs_chain_rsum": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),

@@ -153,36 +153,13 @@ int fcd_ctx_create(fcd_ctx **out) {
     // the only place the environment is read: defaults of the knobs (fcd_ctx_set_knob changes them later)
     ctx->knobs.r_path = (int)knob_env("FCD_R_PATH");
     ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");
-    ctx->knobs.r_persist = (int)knob_env("FCD_R_PERSIST");
     ctx->knobs.r_nopad = (int)knob_env("FCD_R_NOPAD");
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
     ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
-    ctx->knobs.r_streams = (int)knob_env("FCD_R_STREAMS");
-    ctx->knobs.r_prefetch = (int)knob_env("FCD_R_PREFETCH");
-    ctx->knobs.r_stagger = (int)knob_env("FCD_R_STAGGER");
-    ctx->knobs.r_xcd = (int)knob_env("FCD_R_XCD");
-    ctx->knobs.r_nopre = (int)knob_env("FCD_R_NOPRE");
-    ctx->knobs.r_direct = (int)knob_env("FCD_R_DIRECT");
     ctx->knobs.r_poll_limit = (int)knob_env("FCD_R_POLL_LIMIT");
     ctx->knobs.r_withhold = (int)knob_env("FCD_R_WITHHOLD");
     ctx->r_form_last = 0;
-    ctx->side_stream = ctx->ev_fork = ctx->ev_join = nullptr;
-    {
-        hipStream_t st = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
-            ctx->side_stream = st;
-            ctx->ev_fork = e0;
-            ctx->ev_join = e1;
-        } else {
-            (void)hipGetLastError();          // no side stream: the r pass stays on one stream
-            if (e0) (void)hipEventDestroy(e0);
-            if (st) (void)hipStreamDestroy(st);
-        }
-    }
     int rc = fcd_ws_reserve(ctx, 1u << 20);
     if (rc == FCD_OK) {
         void *pin = nullptr;
@@ -224,9 +201,6 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     if (ctx->fsq) (void)hipFree(ctx->fsq);
     if (ctx->acc) (void)hipFree(ctx->acc);
-    if (ctx->ev_fork) (void)hipEventDestroy((hipEvent_t)ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy((hipEvent_t)ctx->ev_join);
-    if (ctx->side_stream) (void)hipStreamDestroy((hipStream_t)ctx->side_stream);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
         delete[] ctx->prof_ev[i];
@@ -254,17 +228,10 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     fcd_knobs &k = ctx->knobs;
     if (!strcmp(name, "r_path")) k.r_path = (int)value;
     else if (!strcmp(name, "r_ub")) k.r_ub = (int)value;
-    else if (!strcmp(name, "r_persist")) k.r_persist = (int)value;
     else if (!strcmp(name, "r_nopad")) k.r_nopad = (int)value;
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;
     else if (!strcmp(name, "f_form")) k.f_form = (int)value;
-    else if (!strcmp(name, "r_streams")) k.r_streams = (int)value;
-    else if (!strcmp(name, "r_prefetch")) k.r_prefetch = (int)value;
-    else if (!strcmp(name, "r_stagger")) k.r_stagger = (int)value;
-    else if (!strcmp(name, "r_xcd")) k.r_xcd = (int)value;
-    else if (!strcmp(name, "r_nopre")) k.r_nopre = (int)value;
-    else if (!strcmp(name, "r_direct")) k.r_direct = (int)value;
     else if (!strcmp(name, "r_poll_limit")) k.r_poll_limit = (int)value;
     else if (!strcmp(name, "r_withhold")) k.r_withhold = (int)value;
     else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");

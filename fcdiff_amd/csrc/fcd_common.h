@@ -13,34 +13,24 @@
 #define FCD_PROF_RSTEP 2
 #define FCD_PROF_PACK 3
 
-// Tuning / test knobs.  Read ONCE from the environment by fcd_ctx_create (FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST,
-// FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL: "0" / unset = default), changed afterwards only through fcd_ctx_set_knob: no
-// entry point reads the environment.
+// Tuning / test knobs.  Read ONCE from the environment by fcd_ctx_create (FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_TOL,
+// FCD_F_TOL, FCD_F_FORM, FCD_R_POLL_LIMIT, FCD_R_WITHHOLD: "0" / unset = default), changed afterwards only through
+// fcd_ctx_set_knob: no entry point reads the environment.
 struct fcd_knobs {
     int r_path;        // 0: blocked r pass -- pipelined one-launch form where its grid fits the device at once, else one launch
-                       // per block step; 1: row-sequential single-launch kernel (alternative, slower); 2: as 0;
-                       // 3: one launch per block step always
+                       // per block step; 3: one launch per block step always
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
-    int r_persist;     // 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; kept with its own test)
-    int r_nopad;       // 1: no empty workgroups beside the in-order workgroups of a step launch
+    int r_nopad;       // 1: no empty workgroups beside the in-order workgroups
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
-    int r_nopre;       // 1: ignore the pair-record table (build the records in LDS at every block step)
-    int r_direct;      // 1: panel role builds its pair records straight from the table rows (no single rows in LDS)
-    int r_prefetch;    // 1: panel workgroups touch the table rows of the next block step (L2 warm-up hint)
-    int r_xcd;         // 1: pipelined r pass deals contiguous pieces of its (chunk, row) list to the XCDs (a chunk's rows on one XCD)
-    int r_stagger;     // > 0: the second panel workgroup of every CU starts r_stagger x 3.5 us late (launches of several rounds)
-    int r_streams;     // 2: the blocked r pass as two half-passes (patient halves) on two streams; 0 / 1: one stream
     int r_poll_limit;  // TEST HOOK: > 0 bounds every device-side poll of the pipelined r pass by this many polls (default 2^20, ~1 s)
     int r_withhold;    // TEST HOOK: 1 = the in-order role of the pipelined r pass never sets its marks (a panel wave then gives up)
-    int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form;
-                       // 4: triple records (U <= 72)
+    int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
 };
 
 // kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
 enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
-       FCD_KA_F_TRI = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_STEP = FCD_KA_F_TRI + 6, FCD_KA_R_PASS = FCD_KA_R_STEP + 4, FCD_KA_R_PIPE = FCD_KA_R_PASS + 4,
-       FCD_KA_N = FCD_KA_R_PIPE + 4 };
+       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PIPE = FCD_KA_R_STEP + 4, FCD_KA_N = FCD_KA_R_PIPE + 4 };
 
 struct fcd_ctx {
     int device;
@@ -56,8 +46,6 @@ struct fcd_ctx {
     int r_form_last;               // form of the last blocked r pass: 1 step-per-launch, 2 pipelined, 3 one-launch with counters (fcd_ctx_stat)
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
-    void *side_stream; // hipStream_t + two events for the two-stream r pass (knob r_streams), made by fcd_ctx_create
-    void *ev_fork, *ev_join;
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
     size_t fsq_bytes;
@@ -109,7 +97,7 @@ static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t sh
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready);
-int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq);
 // bracket ONE kernel launch with events when profiling is on (no-ops otherwise)

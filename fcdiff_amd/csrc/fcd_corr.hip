@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict
                     double c = acc[a][b][r] * inv;
                     c /= sdev[s * Nreg + n];
                     c /= sdev[s * Nreg + m];
-                    c = fmin(fmax(c, -1.0), 1.0);
+                    c = (c != c) ? c : fmin(fmax(c, -1.0), 1.0);      // (a constant series: 0 / 0 = NaN like numpy.corrcoef; fmin / fmax would drop it)
                     if (fisher_z) c = atanh(c);
                     tmp[s * C + (fcd_tri(n) + m)] = c;                       // 16 lanes = 16 consecutive edges = 128 bytes
                 }

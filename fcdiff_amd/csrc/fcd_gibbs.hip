@@ -238,34 +238,24 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
 // SPREAD over 4-bit fields, the pair (u, u+1) in the low two bits of field u/2: (r_n ^ r_m) | (r_n & r_m) << 2 is
 // then the slot number of every pair at once, and a term costs two integer instructions for its address.
 // ---------------------------------------------------------------------------------------------
-// One slot-source word of (w, n): fmt 0 = 16 patients in 4-bit fields (the pair (u, u+1) in the low two bits of field u/2),
-// fmt 1 = 12 patients in bytes (the triple (u, u+1, u+2) in the low three bits of byte u/3: gibbs_f_tri_kernel).
-__device__ __forceinline__ uint32_t pack_ru_word(const uint64_t *__restrict__ r_bits, int64_t wn, int U, int jw, int fmt, int lane) {
+// One slot-source word of (w, n): 16 patients in 4-bit fields (the pair (u, u+1) in the low two bits of field u/2).
+__device__ __forceinline__ uint32_t pack_ru_word(const uint64_t *__restrict__ r_bits, int64_t wn, int U, int jw, int lane) {
     uint32_t v = 0;
-    if (fmt == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int u = jw * 16 + j;
-            const uint64_t word = r_bits[wn * U + (u < U ? u : U - 1)];                              // clamped: no branch per load
-            v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << (4 * (j >> 1) + (j & 1));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int u = jw * 12 + j;
-            const uint64_t word = r_bits[wn * U + (u < U ? u : U - 1)];
-            v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << (8 * (j / 3) + (j % 3));
-        }
+    for (int j = 0; j < 16; ++j) {
+        const int u = jw * 16 + j;
+        const uint64_t word = r_bits[wn * U + (u < U ? u : U - 1)];                              // clamped: no branch per load
+        v |= (u < U ? (uint32_t)((word >> lane) & 1ull) : 0u) << (4 * (j >> 1) + (j & 1));
     }
     return v;
 }
-__global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW, int fmt, int GW,
+__global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict__ r_bits, int Nreg, int U, int NW, int GW,
                                                       uint32_t *__restrict__ r_U) {
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));      // (w, n, word): scalar
     if (item >= GW * Nreg * NW) return;
     const int jw = item % NW, wn = item / NW;                   // wn = w*Nreg + n
-    r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, fmt, lane);
+    r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, lane);
 }
 
 constexpr int FP_EC = 8;     // edges per tile
@@ -431,162 +421,6 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 wm = nm;
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// f step, TRIPLE form (U <= 72; knob f_form = 4).  Same idea one step further: the tile holds records for TRIPLES of
-// patients (u, u+1, u+2): for each of the 64 values of (x_u, x_u+1, x_u+2, a_u, a_u+1, a_u+2),
-//   rec[slot] = lMf[c][u][l(x_u, a_u)][:] + lMf[c][u+1][l(..)][:] + lMf[c][u+2][l(..)][:]      (2 doubles, 1 KB per triple)
-// so that one ds_read_b128 + two fp64 adds cover THREE patients: a third fewer LDS reads and additions per edge than
-// the pair form, for four times the LDS per patient (EC = 4 edges per tile at U = 50 instead of 8).  The slot-source
-// words hold 12 patients, one triple in the low three bits of each byte (pack_ru_word, fmt 1):
-// (r_n ^ r_m) | (r_n & r_m) << 3 is the slot number of four triples at once.
-// ---------------------------------------------------------------------------------------------
-template <int NWT>
-__global__ __launch_bounds__(1024, 8) void gibbs_f_tri_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
-                                                           const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
-                                                           const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
-                                                           int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin,
-                                                           uint8_t *__restrict__ fsq, int EC) {
-    extern __shared__ __attribute__((aligned(1024))) double ttile[];   // records [EC][NTRI][64][2] | singles [EC][3 NTRI][3][2]
-    const int NTRI = (U + 2) / 3, U3 = 3 * NTRI;
-    const int64_t c0 = (int64_t)blockIdx.x * EC;
-    const int ne = (int)((C - c0 < EC) ? (C - c0) : EC);
-    double2 *single = reinterpret_cast<double2 *>(ttile) + (size_t)EC * NTRI * 64;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    uint32_t Zc[NWT];
-    int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
-    fcd_edge_to_pair(c0, wn, wm);
-    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * NWT * 64;
-    const uint32_t ul = (uint32_t)lane;
-#pragma unroll
-    for (int j = 0; j < NWT; ++j) {
-        const uint32_t rn = ru[(uint32_t)((wn * NWT + j) * 64) + ul], rm = ru[(uint32_t)((wm * NWT + j) * 64) + ul];
-        Zc[j] = (rn ^ rm) | ((rn & rm) << 3);
-    }
-    {
-        // the tile's rows of lMf, edge by edge, padded with zero rows to whole triples (two pieces per thread in flight)
-        const int row_d2 = U * 3, pad_d2 = U3 * 3, total = ne * pad_d2;
-        const double2 *src = reinterpret_cast<const double2 *>(lMf + c0 * U * 6);
-        for (int i0 = threadIdx.x; i0 < total; i0 += 2 * blockDim.x) {
-            double2 v[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = i0 + j * (int)blockDim.x;
-                const int ic = i < total ? i : total - 1;
-                const int e = ic / pad_d2, k = ic - e * pad_d2;
-                const double2 x = src[e * row_d2 + (k < row_d2 ? k : 0)];
-                v[j] = k < row_d2 ? x : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = i0 + j * (int)blockDim.x;
-                if (i < total) single[i] = v[j];
-            }
-        }
-    }
-    __syncthreads();
-    {
-        // triple records from the single rows: a thread keeps its slot (blockDim is a multiple of 64)
-        double2 *dst = reinterpret_cast<double2 *>(ttile);
-        const int slot = threadIdx.x & 63;
-        const int x = slot & 7, aa = slot >> 3;
-        const bool valid = (x & aa) == 0;
-        int l[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) l[i] = ((aa >> i) & 1) ? 1 : (((x >> i) & 1) ? 2 : 0);      // 0 typical, 1 both, 2 discordant
-        const int total = ne * NTRI, stride = blockDim.x >> 6;
-        for (int et = threadIdx.x >> 6; et < total; et += stride) {
-            const int e = et / NTRI, t = et - e * NTRI;
-            double2 v = make_double2(0.0, 0.0);
-            if (valid) {
-                const double2 *su = single + (e * U3 + 3 * t) * 3;
-                const double2 v0 = su[l[0]], v1 = su[3 + l[1]], v2 = su[6 + l[2]];
-                v.x = (v0.x + v1.x) + v2.x;
-                v.y = (v0.y + v1.y) + v2.y;
-            }
-            dst[et * 64 + slot] = v;
-        }
-    }
-    __syncthreads();
-    if (w >= GW) return;
-    if (FCD_ABL(0, 3)) return;           // ablation: staging only
-    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
-    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    fcd_u4 rnd = {0, 0, 0, 0};
-    const int NG = (NTRI + 3) >> 2;      // groups of 4 triples = 12 patients = one slot word
-    typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
-    typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
-    const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ttile;   // 1024-aligned
-
-    for (int e = 0; e < ne; ++e) {
-        const int64_t c = c0 + e;
-        // next edge: (n, m+1), or (n+1, 0) at the end of row n (clamped past the last edge: unused there)
-        int nn = wn, nm = wm + 1;
-        if (nm == nn) {
-            nm = 0;
-            nn = (nn + 1 < Nreg) ? nn + 1 : nn;
-        }
-        uint32_t rnn[NWT], rmn[NWT];
-#pragma unroll
-        for (int j = 0; j < NWT; ++j) {
-            rnn[j] = ru[(uint32_t)((nn * NWT + j) * 64) + ul];
-            rmn[j] = ru[(uint32_t)((nm * NWT + j) * 64) + ul];
-        }
-        const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NTRI * 1024));
-        double b1 = 0.0, b2 = 0.0;
-#pragma unroll
-        for (int g = 0; g < NWT; ++g) {
-            if (g < NG) {
-                const uint32_t zs = Zc[g];
-                const uint32_t gb = tb + (uint32_t)(g * (4 * 1024));
-                if (NTRI - 4 * g >= 4) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        // slot -> 16-byte records: byte offset = slot << 4, OR-ed into the (1024-aligned) group base in one
-                        // instruction; the triple's offset p * 1024 is the read's immediate
-                        const uint32_t sh = (p == 0) ? (zs << 4) : (zs >> (8 * p - 4));
-                        uint32_t ad;
-                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0x3F0u), "v"(gb));
-                        const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(p * 1024));
-                        b1 += v.x;
-                        b2 += v.y;
-                    }
-                } else {
-                    for (int p = 0; p < NTRI - 4 * g; ++p) {
-                        const uint32_t off = ((zs >> (8 * p)) & 63u) << 4;
-                        const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + gb + (uint32_t)(p * 1024));
-                        b1 += v.x;
-                        b2 += v.y;
-                    }
-                }
-            }
-        }
-        b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
-        b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
-        if (FCD_ABL(0, 2)) {             // ablation: no RNG / exp
-            f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
-        } else {
-            if (e == 0 || (c & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);
-            const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
-            bool amb;
-            int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
-            if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
-            (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
-            if (fsq) {
-                uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
-                (sq + ((int64_t)wn * Nreg + wm) * 64)[(uint32_t)lane] = (uint8_t)k;
-                (sq + ((int64_t)wm * Nreg + wn) * 64)[(uint32_t)lane] = (uint8_t)k;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NWT; ++j) Zc[j] = (rnn[j] ^ rmn[j]) | ((rnn[j] & rmn[j]) << 3);
-        wn = nn;
-        wm = nm;
     }
 }
 
@@ -875,7 +709,7 @@ struct tally_args {
     const uint8_t *f_state;
     const uint64_t *r_bits;
     int64_t C, NU, G;
-    int GW, Nreg, U, NW, fmt;          // (NW words per region of the slot-source format fmt: pack_ru_word)
+    int GW, Nreg, U, NW;               // (NW slot-source words per region: pack_ru_word)
     unsigned long long *acc;           // context-owned: 4 sums + ticket
     unsigned long long *counts_out;    // nullable
     uint32_t *cnt_f, *cnt_r;           // nullable (both or neither)
@@ -959,7 +793,7 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
         const int items = GW * a.Nreg * NW;
         for (int item = ((int)blockIdx.x - nfb) * 16 + wave; item < items; item += ((int)gridDim.x - nfb) * 16) {
             const int jw = item % NW, wn = item / NW;                   // wn = w*Nreg + n
-            a.r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, a.fmt, lane);
+            a.r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, lane);
         }
     }
     if (!a.acc) return;
@@ -1194,31 +1028,15 @@ extern "C" int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *l
 
 // Which kernel the f step runs at a shape, and with what geometry: shared by the launch code, by the workspace
 // formula (fcd_f_pass_ws_bytes) and by the fused driver (only the pair forms write the square copy).
-enum { F_GENERIC = 0, F_PAIR = 1, F_PAIRX = 2, F_DIFF = 3, F_TRI = 4 };
+enum { F_GENERIC = 0, F_PAIR = 1, F_PAIRX = 2, F_DIFF = 3 };
 struct f_plan {
     int form, NW16, EC;
     size_t shmem;
-    int NW, fmt;            // slot-source words per region and their format (pack_ru_word): what pack_ru / the tally make
+    int NW;                 // slot-source words per region (pack_ru_word): what pack_ru / the tally make
 };
 static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int f_form) {
-    f_plan p = {F_GENERIC, (int)((U + 15) / 16), 0, 0, (int)((U + 15) / 16), 0};
+    f_plan p = {F_GENERIC, (int)((U + 15) / 16), 0, 0, (int)((U + 15) / 16)};
     if (!have_lMf || (size_t)U * 48 > 160 * 1024) return p;
-    {
-        // triple form (knob f_form = 4): up to 6 words of 4 triples, as many edges per tile (at most 4) as let two
-        // workgroups share a CU
-        const int64_t ntri = (U + 2) / 3, nwt = (ntri + 3) / 4;
-        const size_t per_edge = (size_t)ntri * 1024 + (size_t)ntri * 3 * 48;
-        if (f_form == F_TRI && nwt <= 6 && per_edge <= 80 * 1024 && GW * Nreg * nwt < INT32_MAX / 4) {
-            int ec = (int)((80 * 1024) / per_edge);
-            if (ec > 4) ec = 4;
-            p.form = F_TRI;
-            p.EC = ec;
-            p.shmem = (size_t)ec * per_edge;
-            p.NW = (int)nwt;
-            p.fmt = 1;
-            return p;
-        }
-    }
     const bool words_ok = GW * Nreg * p.NW16 < INT32_MAX / 4;       // r_U item index in 32 bits
     const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
     if (f_form != F_PAIRX && f_form != F_DIFF && p.NW16 <= 4 && pair_shmem <= 96 * 1024 && words_ok) {
@@ -1248,15 +1066,14 @@ static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int
 }
 
 size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW) {
-    // per-lane slot words r_U of the pair forms (the largest user; the other forms need nothing)
-    // (16 patients per word in the pair forms, 12 in the triple form)
-    return (size_t)GW * Nreg * ((U + 11) / 12) * 64 * sizeof(uint32_t);
+    // per-lane slot words r_U of the pair forms (the largest user; the other forms need nothing): 16 patients per word
+    return (size_t)GW * Nreg * ((U + 15) / 16) * 64 * sizeof(uint32_t);
 }
 
 size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {
     const f_plan p = f_plan_for(true, Nreg, U, GW, 0);
     const size_t need = (size_t)GW * Nreg * Nreg * 64;
-    return ((p.form == F_PAIR || p.form == F_PAIRX || p.form == F_TRI) && need <= ((size_t)8 << 30)) ? need : 0;
+    return ((p.form == F_PAIR || p.form == F_PAIRX) && need <= ((size_t)8 << 30)) ? need : 0;
 }
 
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
@@ -1275,7 +1092,7 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     hipStream_t s = (hipStream_t)stream;
     float margin = FCD_DRAW_F_MARGIN;
     if ((float)ctx->knobs.f_tol > margin) margin = (float)ctx->knobs.f_tol;   // test hook: huge = every draw through fcd_draw_f
-    if (pl.form == F_PAIR || pl.form == F_PAIRX || pl.form == F_TRI) {
+    if (pl.form == F_PAIR || pl.form == F_PAIRX) {
         // pair / triple forms: per-lane slot words over patients (scratch in the ctx workspace), records in LDS
         rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));
         if (rc) return rc;
@@ -1283,7 +1100,7 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
         if (!ru_ready) {     // (inside fcd_gibbs_run the previous sweep's tally has made them already)
             const int64_t items = (int64_t)g.GW * Nreg * pl.NW;
             hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, pl.NW,
-                               pl.fmt, g.GW, r_U);
+                               g.GW, r_U);
             FCD_LAUNCH_CHECK();
         }
         dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
@@ -1296,23 +1113,7 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
         hipLaunchKernelGGL(KERN, grid, dim3(64 * wpb), pl.shmem, s, FCD_F_ARGS);                              \
         fcd_prof_end(ctx, FCD_PROF_F, s);                                                                     \
     } while (0)
-        if (pl.form == F_TRI) {
-#define FCD_LAUNCH_T(KERN, SLOT)                                                                              \
-    do {                                                                                                      \
-        rc = fcd_lds_attr(ctx, SLOT, reinterpret_cast<const void *>(&KERN), pl.shmem);                        \
-        if (rc) return rc;                                                                                    \
-        fcd_prof_begin(ctx, FCD_PROF_F, s);                                                                   \
-        hipLaunchKernelGGL(KERN, grid, dim3(64 * wpb), pl.shmem, s, FCD_F_ARGS, pl.EC);                       \
-        fcd_prof_end(ctx, FCD_PROF_F, s);                                                                     \
-    } while (0)
-            if (pl.NW == 1) FCD_LAUNCH_T(gibbs_f_tri_kernel<1>, FCD_KA_F_TRI + 0);
-            else if (pl.NW == 2) FCD_LAUNCH_T(gibbs_f_tri_kernel<2>, FCD_KA_F_TRI + 1);
-            else if (pl.NW == 3) FCD_LAUNCH_T(gibbs_f_tri_kernel<3>, FCD_KA_F_TRI + 2);
-            else if (pl.NW == 4) FCD_LAUNCH_T(gibbs_f_tri_kernel<4>, FCD_KA_F_TRI + 3);
-            else if (pl.NW == 5) FCD_LAUNCH_T(gibbs_f_tri_kernel<5>, FCD_KA_F_TRI + 4);
-            else FCD_LAUNCH_T(gibbs_f_tri_kernel<6>, FCD_KA_F_TRI + 5);
-#undef FCD_LAUNCH_T
-        } else if (pl.form == F_PAIR) {
+        if (pl.form == F_PAIR) {
             if (pl.NW16 == 1) FCD_LAUNCH_F(gibbs_f_pair_kernel<1>, FCD_KA_F_PAIR + 0);
             else if (pl.NW16 == 2) FCD_LAUNCH_F(gibbs_f_pair_kernel<2>, FCD_KA_F_PAIR + 1);
             else if (pl.NW16 == 3) FCD_LAUNCH_F(gibbs_f_pair_kernel<3>, FCD_KA_F_PAIR + 2);
@@ -1358,7 +1159,7 @@ extern "C" int fcd_gibbs_stats(fcd_ctx *ctx, const uint8_t *f_state, const uint6
 }
 
 extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                                const double *lMp, const double *hyper,
+                                const double *hyper,
                                 uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                                 uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                                 fcd_stream stream) {
@@ -1369,11 +1170,11 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
     // The copy lives in the context (fcd_ctx_reserve sizes it; a first call at a larger shape grows it here, which
     // synchronises -- the one case the header names).
     uint8_t *fsq = nullptr;
-    if (ctx && lMf && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 && ctx->knobs.r_path != 1) {
+    if (ctx && lMf && lMd && edge_mode == FCD_EDGE_SYMMETRIC && Nreg >= 2 && U >= 1 && G >= 1 && true) {
         const int64_t GW = (G + 63) / 64;
         const f_plan pl = f_plan_for(true, Nreg, U, GW, ctx->knobs.f_form);
         const size_t need = (size_t)GW * Nreg * Nreg * 64;
-        if ((pl.form == F_PAIR || pl.form == F_PAIRX || pl.form == F_TRI) && need <= ((size_t)8 << 30)) {
+        if ((pl.form == F_PAIR || pl.form == F_PAIRX) && need <= ((size_t)8 << 30)) {
             int rc = fcd_fsq_reserve(ctx, need);
             if (rc) return rc;
             fsq = (uint8_t *)ctx->fsq;
@@ -1383,7 +1184,7 @@ extern "C" int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *l
         int rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i,
                                      (hipStream_t)stream, fsq, false);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode,
                                  (hipStream_t)stream, fsq);
         if (rc) return rc;
     }
@@ -1419,11 +1220,11 @@ extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const 
 // one launch of gibbs_tally_kernel; counts / cnt_f+cnt_r / hyper / r_U each optional
 static int launch_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                         const fcd_geo &g, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, double *hyper, uint32_t *r_U,
-                        int ru_words, int ru_fmt, hipStream_t s) {
+                        int ru_words, hipStream_t s) {
     tally_args a;
     a.f_state = f_state; a.r_bits = r_bits;
     a.C = g.C; a.NU = Nreg * U; a.G = G;
-    a.GW = g.GW; a.Nreg = (int)Nreg; a.U = (int)U; a.NW = ru_words; a.fmt = ru_fmt;
+    a.GW = g.GW; a.Nreg = (int)Nreg; a.U = (int)U; a.NW = ru_words;
     a.acc = (counts || hyper) ? (unsigned long long *)ctx->acc : nullptr;
     a.counts_out = reinterpret_cast<unsigned long long *>(counts);
     a.cnt_f = cnt_f; a.cnt_r = cnt_r;
@@ -1450,14 +1251,14 @@ extern "C" int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint6
     if (!f_state || !r_bits) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: null pointer");
     if ((cnt_f == nullptr) != (cnt_r == nullptr)) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_tally: cnt_f and cnt_r go together");
     if (!counts && !cnt_f) return FCD_OK;
-    return launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, counts, cnt_f, cnt_r, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+    return launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, counts, cnt_f, cnt_r, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 // The sampler loop of ONE rank between two exchanges of pooled statistics (what UnsharedRegionFit(method='gibbs'),
 // run_chains and bench.py call).  Per sweep: f pass (1 launch), packing for the r pass (1), block steps of the r pass
 // (ceil(Nreg/16) + 1), tally (1) -- the tally also carries the M-step and the slot words of the next f pass.
 extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                             const double *lMp, double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
+                             double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                              int64_t chain0, uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode,
                              int64_t mstep_every, int64_t accumulate_from, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r,
                              fcd_stream stream) {
@@ -1473,8 +1274,8 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
     // square copy of the f state for the r pass's packing (see fcd_gibbs_sweeps)
     uint8_t *fsq = nullptr;
     const f_plan pl = f_plan_for(lMf != nullptr, Nreg, U, g.GW, ctx->knobs.f_form);
-    const bool pair_form = pl.form == F_PAIR || pl.form == F_PAIRX || pl.form == F_TRI;
-    if (pair_form && lMd && edge_mode == FCD_EDGE_SYMMETRIC && ctx->knobs.r_path != 1) {
+    const bool pair_form = pl.form == F_PAIR || pl.form == F_PAIRX;
+    if (pair_form && lMd && edge_mode == FCD_EDGE_SYMMETRIC && true) {
         const size_t need = (size_t)g.GW * Nreg * Nreg * 64;
         if (need <= ((size_t)8 << 30)) {
             rc = fcd_fsq_reserve(ctx, need);
@@ -1490,7 +1291,7 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
     for (int64_t i = 0; i < n_sweeps; ++i) {
         rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
         if (rc) return rc;
         const bool last = i + 1 == n_sweeps;
         const bool do_m = mstep_every > 0 && (i + 1) % mstep_every == 0;
@@ -1500,7 +1301,7 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
         int64_t *cts = (last ? counts : nullptr);
         if (do_m || do_a || cts || r_U_next) {
             rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
-                              do_m ? hyper : nullptr, r_U_next, pl.NW, pl.fmt, s);
+                              do_m ? hyper : nullptr, r_U_next, pl.NW, s);
             if (rc) return rc;
         }
         ru_ready = r_U_next != nullptr;

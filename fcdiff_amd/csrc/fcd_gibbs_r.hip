@@ -16,7 +16,8 @@
 //     tiles, and draw r_n = [v > 0]; one wave per (patient, chain word), nothing but the 1-bit decision links one
 //     region to the next.
 // ceil(Nreg / 16) + 1 launches per pass; the serial part rides beside the parallel part of the next block.
-// gibbs_r_pass_kernel is the same pass in one launch (roles hand over through counters in device memory).
+// gibbs_r_pipe_kernel is the same pass in ONE launch (every workgroup resident, hand-over through marks and sentinels in
+// device memory): the default wherever its grid fits the device at once.
 //
 // lMd (U, Nreg, Nreg, 3, 2) is a region-major DIFFERENCE table made once per table build:
 //   lMd[u][n][m][k][t] = t ? lM[c,u,k,1] - lM[c,u,k,2] : lM[c,u,k,2] - lM[c,u,k,0],   c = edge(n, m)
@@ -54,33 +55,6 @@ __global__ __launch_bounds__(256) void region_tables_kernel(const double *__rest
                 o[k * 2 + 1] = p[k * 3 + 1] - p[k * 3 + 2];   // r_m = 1: lM[k,1] - lM[k,2]
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// region-major PAIR-RECORD table (optional, made once per table build from lMd): lMp (U, Nreg, NP, 9, 4), NP = 8 ceil(Nreg/16),
-//   lMp[u][n][p][q = 3k + k'][tt = t + 2t'] = lMd[u][n][2p][k][t] + lMd[u][n][2p+1][k'][t']      (zero records beyond Nreg)
-// i.e. exactly the records the panel and in-order roles otherwise build in LDS at every block step (same additions,
-// same bits).  With it a workgroup copies its tile straight into LDS: no single rows, no build phase, one barrier
-// less -- at the price of streaming 288 B instead of 96 B per pair of regions from memory.  One thread per (record, q).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void region_pair_tables_kernel(const double *__restrict__ lMd, int Nreg, int U, int NP,
-                                                                 double *__restrict__ lMp) {
-    const int64_t total = (int64_t)U * Nreg * NP * 9;
-    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(it % 9);
-        const int64_t rec = it / 9;
-        const int p = (int)(rec % NP);
-        const int64_t un = rec / NP;                      // u * Nreg + n
-        const int k = q / 3, k2 = q - 3 * k;
-        const int m0 = 2 * p, m1 = m0 + 1;
-        const double *row = lMd + un * Nreg * 6;
-        double2 a2 = make_double2(0.0, 0.0), b2 = a2;
-        if (m0 < Nreg) a2 = *reinterpret_cast<const double2 *>(row + m0 * 6 + 2 * k);
-        if (m1 < Nreg) b2 = *reinterpret_cast<const double2 *>(row + m1 * 6 + 2 * k2);
-        double2 *dst = reinterpret_cast<double2 *>(lMp + rec * 36 + q * 4);
-        dst[0] = make_double2(a2.x + b2.x, a2.y + b2.x);
-        dst[1] = make_double2(a2.x + b2.y, a2.y + b2.y);
     }
 }
 
@@ -248,13 +222,12 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__
 // ---------------------------------------------------------------------------------------------
 struct r_step_args {
     const double *lMd, *hyper;
-    const double *lMp;      // pair-record table (nullable): tiles are copied from it instead of being built in LDS
     const uint2 *f_S;       // f pair bytes (q << 2)
     const uint2 *r_S;       // r bytes (one per pair of regions) before the pass (pack_r): what the blocks above the current one still hold
     uint2 *r_Sn;            // r bytes redrawn in this pass: each written once (by D), read only afterwards -> plain cached loads are safe
     uint64_t *r_bits;
     double *Pbuf[2];        // e = (dpi + panel sum) - threshold: P(s) writes [s & 1], D(s) reads it
-    uint32_t *flags;        // one-launch form: cntP[wg][uc][s] | cntD[wg][uc][s] | error word; else nullptr
+    uint32_t *flags;        // pipelined form: one mark per (chain word, patient, block); else nullptr
     int Nreg, U, NBLK, GW;
     int u_lo, u_n;          // the patients this launch serves: [u_lo, u_lo + u_n)  (patients are independent given f: a pass
                             // may run as two half-passes on two streams, see fcd_gibbs_r_step_sq)
@@ -263,23 +236,12 @@ struct r_step_args {
     int ncu, npad;          // ... CUs of the device; empty workgroups at [ncu, ncu + npad) (beside the D workgroups)
     uint32_t chain0, sweep;
     uint64_t seed;
-    int prefetch;           // panel role: touch the next step's table rows (knob r_prefetch)
-    int direct;             // panel role: build the pair records straight from the table rows, no single rows in LDS (knob r_direct)
-    int xcd;                // pipelined form: contiguous pieces of the (chunk, row) list per XCD (knob r_xcd)
-    int stagger;            // step-per-launch form: the second workgroup of a CU starts this many x 3.5 us late (knob r_stagger)
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
     int poll_limit;         // pipelined form: polls before a wait is given up (R_POLL_LIMIT; smaller only through the test hook)
     int withhold;           // TEST HOOK (knob r_withhold): the in-order role never sets its marks
 };
 
-// ---- cross-workgroup hand-over of the one-launch form ----
-// The XCDs' L2 caches are not coherent with each other, and the agent-scope fences that make them so
-// (buffer_wbl2 / buffer_inv) cost tens of microseconds per use here.  So the few arrays that cross workgroups
-// inside the launch (panel sums, thresholds, r words) are read and written with agent-scope accesses (sc1: served
-// by the memory side), everything else stays cached, and the order is kept by hand:
-//   producer: coherent stores; wait until they are acknowledged (vmcnt 0); workgroup barrier; one thread counts up;
-//   consumer: one thread polls the counter (bounded: a wait that outlasts R_SPIN_LIMIT polls raises the error word
-//             and every workgroup drains); workgroup barrier; coherent loads.
+// agent-scope (memory-side) access to what crosses workgroups inside the pipelined launch; plain otherwise
 template <bool COH>
 __device__ __forceinline__ double ld_d(const double *p) {
     if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -289,37 +251,6 @@ template <bool COH>
 __device__ __forceinline__ void st_d(double *p, double v) {
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ uint32_t ld_h(const uint16_t *p) {
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool COH>
-__device__ __forceinline__ void st_h(uint16_t *p, uint16_t v) {
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-constexpr int R_SPIN_LIMIT = 1 << 18;      // x ~0.3 us per poll
-__device__ __forceinline__ void r_signal(uint32_t *flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool r_wait(const uint32_t *flag, uint32_t need, uint32_t *err, int *sh_ok) {
-    if (threadIdx.x == 0) {
-        int ok = 1, spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(10);
-            if (++spins > R_SPIN_LIMIT) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-        }
-        *sh_ok = ok;
-    }
-    __syncthreads();
-    const bool ok = *sh_ok != 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return ok;
 }
 
 #ifndef FCD_PGRP1
@@ -333,11 +264,8 @@ constexpr int D_LDS_COMPACT = (R_NB * (R_NB / 2) + 104) * 36 + R_NB * R_NB * 6;
 constexpr int D_LDS_SPREAD = 2 * R_NB * (R_NB / 2) * 36 + 2 * R_NB * R_NB * 6;
 
 // st = step (block of rows), (row, uc, wg) = region of the block, chunk of patients, group of chain words.
-// wait_flag != nullptr (one-launch form): the r words of blocks <= st-2 are final once *wait_flag >= wait_need.
-// Returns false if that wait was abandoned.
-template <int UB, bool COH>
-__device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int row, int uc, int wg, double *smem,
-                                             const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
+template <int UB>
+__device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int row, int uc, int wg, double *smem) {
     constexpr int P_GRP = UB == 1 ? P_GRP_1 : P_GRP_2;
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const int x0 = st > 0 ? st - 1 : 0, x1 = st + 1;       // blocks left out of the sums
@@ -347,89 +275,12 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     const int n = st * R_NB + row;
     const int u0 = a.u_lo + uc * UB;
     const int nu = (a.u_lo + a.u_n - u0 < UB) ? (a.u_lo + a.u_n - u0) : UB;
-    if (FCD_ABL(1, 5)) return true;       // ablation: empty role
+    if (FCD_ABL(1, 5)) return;            // ablation: empty role
     [[maybe_unused]] const int trec = st * 1024 + (int)blockIdx.x;
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 1);
     FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
-    const bool pre = a.lMp != nullptr;
-    if (pre) {
-        // the tile from the pair-record table: record (pair, patient) = 18 pieces of 16 bytes, read once by this
-        // workgroup only (non-temporal), four or so pieces per thread in flight
-        const int n_d2 = n_pairs * UB * 18;
-        double2 *dst = reinterpret_cast<double2 *>(pairs);
-        const double *rowp[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int us = u < nu ? u : nu - 1;                        // tail chunk: replicate the last patient (never stored)
-            rowp[u] = a.lMp + ((int64_t)(u0 + us) * Nreg + n) * n_pairs * 36;
-        }
-        constexpr int SU = 4;
-        for (int it0 = threadIdx.x; it0 < n_d2; it0 += SU * blockDim.x) {
-            double2 v[SU];
-#pragma unroll
-            for (int j = 0; j < SU; ++j) {
-                const int it = it0 + j * (int)blockDim.x;
-                const int itc = it < n_d2 ? it : n_d2 - 1;             // clamped: no branch around the load
-                const int recl = itc / 18, c = itc - recl * 18;        // LDS record (pair * UB + u), piece
-                const int pr = recl / UB, u = recl - pr * UB;
-                const double *src = rowp[0];
-#pragma unroll
-                for (int uu = 1; uu < UB; ++uu)
-                    if (u == uu) src = rowp[uu];
-                src += pr * 36 + c * 2;
-                v[j] = make_double2(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1));
-            }
-#pragma unroll
-            for (int j = 0; j < SU; ++j) {
-                const int it = it0 + j * (int)blockDim.x;
-                if (it < n_d2) dst[it] = v[j];
-            }
-        }
-    } else if (a.direct) {
-        // pair records straight from the table rows (L2): a thread keeps one of the 9 (k, k') rows of a record and makes
-        // its four (t, t') entries from two 16-byte loads -- no single rows in LDS, no second barrier.  Up to four records
-        // per thread, all eight loads in flight together; regions beyond Nreg read as zero records.
-        const int q = threadIdx.x % 9, step = blockDim.x / 9;
-        const int k = q / 3, k2 = q - 3 * k;
-        const int total = n_pairs * UB;
-        const double *rowp[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int us = u < nu ? u : nu - 1;                        // tail chunk: replicate the last patient (never stored)
-            rowp[u] = a.lMd + ((int64_t)(u0 + us) * Nreg + n) * Nreg * 6;
-        }
-        if ((int)threadIdx.x < step * 9) {
-            constexpr int BU = 4;
-            for (int pu0 = threadIdx.x / 9; pu0 < total; pu0 += BU * step) {
-                double2 a2[BU], b2[BU];
-#pragma unroll
-                for (int j = 0; j < BU; ++j) {
-                    const int pu = pu0 + j * step;
-                    const int puc = pu < total ? pu : total - 1;
-                    const int pr = puc / UB, u = puc - pr * UB;
-                    const double *row = rowp[0];
-#pragma unroll
-                    for (int uu = 1; uu < UB; ++uu)
-                        if (u == uu) row = rowp[uu];
-                    const int m0 = 2 * pr, m1 = m0 + 1;
-                    const double2 va = *reinterpret_cast<const double2 *>(row + (m0 < Nreg ? m0 : 0) * 6 + 2 * k);
-                    const double2 vb = *reinterpret_cast<const double2 *>(row + (m1 < Nreg ? m1 : 0) * 6 + 2 * k2);
-                    a2[j] = m0 < Nreg ? va : make_double2(0.0, 0.0);
-                    b2[j] = m1 < Nreg ? vb : make_double2(0.0, 0.0);
-                }
-#pragma unroll
-                for (int j = 0; j < BU; ++j) {
-                    const int pu = pu0 + j * step;
-                    if (pu < total) {
-                        double2 *dst = reinterpret_cast<double2 *>(pairs + pu * 36 + q * 4);        // tt = t + 2 t'
-                        dst[0] = make_double2(a2[j].x + b2[j].x, a2[j].y + b2[j].x);
-                        dst[1] = make_double2(a2[j].x + b2[j].y, a2[j].y + b2[j].y);
-                    }
-                }
-            }
-        }
-    } else {
+    {
         // rows padded with zero records to a whole number of blocks: the pair build below needs no guards.  Two loads per
         // thread and turn, both in flight before the first is stored (addresses clamped, zeros selected afterwards: a
         // guarded load would make every turn wait for its own trip to memory)
@@ -487,11 +338,6 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
             th[u] = fcd_logit_fast((uu & 1) ? fcd_u53(x.z, x.w) : fcd_u53(x.x, x.y));
         }
     }
-    FCD_TRACE(trec, 4);
-    if (wait_flag) {
-        if (!r_wait(wait_flag, wait_need, err, sh_ok)) return false;
-    }
-    FCD_TRACE(trec, 5);
     // wave-uniform bases (scalar registers) + unsigned 32-bit lane offsets: no per-lane 64-bit pointers
     const uint32_t ulane = (uint32_t)lane;
     const uint2 *__restrict__ fr = a.f_S + ((int64_t)(live ? w : 0) * Nreg + n) * NBLK * 64;
@@ -520,8 +366,8 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     }
     __syncthreads();
     FCD_TRACE(trec, 1);
-    if (FCD_ABL(1, 4)) return true;       // ablation: single rows staged, no pair records
-    if (!pre && !a.direct) {
+    if (FCD_ABL(1, 4)) return;            // ablation: single rows staged, no pair records
+    {
         // pair records: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries from two 16-byte
         // reads -- [k][t = 0, 1] of region m and [k'][t' = 0, 1] of region m+1 -- and two 16-byte writes: a third of the
         // LDS instructions of one entry per thread, and two turns through the (pair, patient) list instead of seven
@@ -541,28 +387,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
         __syncthreads();
     }
     FCD_TRACE(trec, 2);
-    uint32_t pf[2] = {0u, 0u};
-    if ((a.prefetch & 1) && st + 1 < NBLK && !pre) {
-        // Touch the table rows the SAME workgroup slot of the next launch will stage (region n + 16, the same patients):
-        // launches deal their workgroups to the XCDs in the same order, so the lines wait in this XCD's L2 (a hint only:
-        // nothing depends on it).  One dword per 128-byte line and thread (two at most), the values are thrown away at
-        // the very end of the role: nothing waits for them here.
-        const int nn = n + R_NB;
-        if (nn < Nreg) {
-            const int lines_per_row = (Nreg * 48 + 127) >> 7;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int it = threadIdx.x + j * (int)blockDim.x;
-                if (it < UB * lines_per_row) {
-                    const int u = it / lines_per_row, ln = it - u * lines_per_row;
-                    const int us = u < nu ? u : nu - 1;
-                    const char *rowp = reinterpret_cast<const char *>(a.lMd + ((int64_t)(u0 + us) * Nreg + nn) * Nreg * 6);
-                    pf[j] = *reinterpret_cast<const uint32_t *>(rowp + (size_t)ln * 128);
-                }
-            }
-        }
-    }
-    if (!live) return true;
+    if (!live) return;
     // LDS byte offset of the tile: reads go through an LDS-space pointer so that (block base + pair, patient offset)
     // becomes scalar base + instruction immediate
     typedef __attribute__((address_space(3))) const double lds_cdouble;
@@ -571,7 +396,7 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
     constexpr uint32_t REC = UB * 288u;   // bytes per pair of regions in the tile
-    if (FCD_ABL(1, 3)) return true;       // ablation: staging only
+    if (FCD_ABL(1, 3)) return;            // ablation: staging only
 
     // Blocks of 16 regions in groups of P_GRP: the state words of the NEXT group are requested before the
     // current group's terms run, so no global latency sits on the loop.
@@ -609,10 +434,8 @@ __device__ __forceinline__ bool r_role_panel(const r_step_args &a, int st, int r
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-        if (u < nu) st_d<COH>(a.Pbuf[st & 1] + (((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane, (dpi + d[u]) - th[u]);
-    asm volatile("" ::"v"(pf[0]), "v"(pf[1]));            // keeps the prefetch loads alive; their data is long here
+        if (u < nu) a.Pbuf[st & 1][(((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane] = (dpi + d[u]) - th[u];
     FCD_TRACE(trec, 3);
-    return true;
 }
 
 // Role D: one workgroup = one patient x one group of chain words; one wave = one (patient, chain word) scan.
@@ -629,11 +452,8 @@ constexpr int D_RECS_T = R_NB * (R_NB / 2);             // pair records of one t
 #define FCD_PF_F 2
 #endif
 constexpr int D_SAFE = 104;                             // records of tile 1 that end before single B starts (compact layout)
-// b = block, (u, wg) = patient, group of chain words.  wait_flag != nullptr (one-launch form): the panel sums and
-// thresholds of the block are complete once *wait_flag >= wait_need.  Returns false if that wait was abandoned.
-template <bool COH>
-__device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, int wg, double *smem,
-                                            const uint32_t *wait_flag, uint32_t wait_need, uint32_t *err, int *sh_ok) {
+// b = block, (u, wg) = patient, group of chain words.
+__device__ __forceinline__ void r_role_diag(const r_step_args &a, int b, int u, int wg, double *smem) {
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const int B0 = b * R_NB;
     const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
@@ -646,7 +466,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     double *pairs = smem;
     double *sA = compact ? smem + D_RECS_T * 36 : smem + 2 * D_RECS_T * 36;
     double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
-    if (FCD_ABL(2, 5)) return true;      // ablation: empty role
+    if (FCD_ABL(2, 5)) return;           // ablation: empty role
     [[maybe_unused]] const int trec = (b + 1) * 1024 + (int)blockIdx.x;
     FCD_TRACE(trec, 0);
     FCD_TRACE_VAL(trec, 6, 2);
@@ -659,64 +479,27 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     uint2 *__restrict__ rSn = a.r_Sn + (wu * NBLK + b) * 64;
     const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
     const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
-    // e_i (from the memory side: P(b) wrote them in the previous launch) and the f words are requested PF_E - 1 resp.
-    // PF_F - 1 rows ahead of the scan; the first ones leave HERE, before the tiles are staged and built (step-per-launch
-    // form: everything the scan reads was final before the launch; the one-launch form asks after its wait).
+    // e_i (P(b) wrote them in the previous launch) and the f words are requested PF_E - 1 resp. PF_F - 1 rows ahead of the
+    // scan; the first ones leave HERE, before the tiles are staged and built (everything the scan reads was final
+    // before the launch).
     const uint32_t ulane = (uint32_t)lane;
     constexpr int PF_E = FCD_PF_E, PF_F = FCD_PF_F;
     uint2 rcur = make_uint2(0u, 0u), rpb = make_uint2(0u, 0u);      // r bytes (one per pair: tt) of the own block (old) / of block b-1 (redrawn)
     double ev[PF_E];
     uint2 fa[PF_F], fb[PF_F];
-    auto first_loads = [&]() {
+    {
         rcur = a.r_S[(wu * NBLK + b) * 64 + ulane];
-        {
-            const uint2 *src = rSn - (hasA ? 64 : 0) + ulane;       // (block 0: a dummy read; masked where the scan starts)
-            if (COH) {
-                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                rpb = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-            } else {
-                rpb = *src;
-            }
-        }
+        rpb = (rSn - (hasA ? 64 : 0))[ulane];                       // (block 0: a dummy read; masked where the scan starts)
 #pragma unroll
-        for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<COH>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
+        for (int i = 0; i < PF_E - 1; ++i) ev[i] = Pw[(i < nb ? i : nb - 1) * 64 + ulane];
 #pragma unroll
         for (int i = 0; i < PF_F - 1; ++i) {
             const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
             fb[i] = fro[ulane];
             fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
         }
-    };
-    if (!COH) first_loads();
-    const bool pre = a.lMp != nullptr;
-    if (pre) {
-        // both tiles from the pair-record table: row i of the block = 8 records (2 304 contiguous bytes) per tile
-        const int n_pairs = NBLK * (R_NB / 2);
-        constexpr int ROW_D2 = (R_NB / 2) * 18;                       // 16-byte pieces per (tile, row)
-        double2 *dst = reinterpret_cast<double2 *>(pairs);
-        constexpr int SU = 5;                                         // 2 * 16 * ROW_D2 = 4608 pieces: 4.5 per thread at 1024
-        for (int it0 = threadIdx.x; it0 < 2 * R_NB * ROW_D2; it0 += SU * blockDim.x) {
-            double2 v[SU];
-#pragma unroll
-            for (int j = 0; j < SU; ++j) {
-                const int it = it0 + j * (int)blockDim.x;
-                const int itc = it < 2 * R_NB * ROW_D2 ? it : 0;
-                const int tile = itc / (R_NB * ROW_D2), rem = itc - tile * (R_NB * ROW_D2);
-                const int i = rem / ROW_D2, c = rem - i * ROW_D2;
-                const bool on = i < nb && (tile == 1 || hasA);
-                const int blk = tile == 1 ? b : (hasA ? b - 1 : 0);
-                const double *src = a.lMp + ((((int64_t)u * Nreg + B0 + (i < nb ? i : 0)) * n_pairs + blk * (R_NB / 2)) * 36 + c * 2);
-                const double2 x = make_double2(__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1));
-                v[j] = on ? x : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int j = 0; j < SU; ++j) {
-                const int it = it0 + j * (int)blockDim.x;
-                if (it < 2 * R_NB * ROW_D2) dst[it] = v[j];
-            }
-        }
-    } else {
+    }
+    {
         // single records of both tiles, 16 bytes a piece: (tile, row i, piece c of the row's 768 bytes); two pieces per
         // thread and turn in flight together (clamped addresses, zeros selected afterwards: no load behind a branch)
         const double2 *rowbase = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6) + B0 * 3;
@@ -748,7 +531,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     }
     __syncthreads();
     FCD_TRACE(trec, 1);
-    if (!pre) {
+    {
         // pair records, as in the panel role: a thread keeps one of the 9 (k, k') rows and makes its four (t, t') entries
         // with 16-byte reads and writes; record (i, p) <- singles (i*16 + 2p) * 6
         const int q = threadIdx.x % 9, step = blockDim.x / 9;
@@ -791,19 +574,13 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     }
     __syncthreads();
     FCD_TRACE(trec, 2);
-    FCD_TRACE(trec, 4);
-    if (wait_flag) {
-        if (!r_wait(wait_flag, wait_need, err, sh_ok)) return false;
-    }
-    FCD_TRACE(trec, 5);
-    if (!live || FCD_ABL(2, 3)) return true;
+    if (!live || FCD_ABL(2, 3)) return;
     // The scan is the serial chain of the pass (one per patient): its waves go ahead of the panel waves that share the CU.
     __builtin_amdgcn_s_setprio(3);
     // Per region i, in order:  v = e_i (= dpi + panel sum - threshold, from P(b)) + 8 pair terms against block b-1 (its
     // r bits are final) + 8 pair terms against the own block -- redrawn bits below i, old bits above i, the record of
     // (i, i) is zero -- and the sign test.  All 16 reads of a row are independent; only the 1-bit decision links one
     // row to the next.
-    if (COH) first_loads();
     if (!hasA) rpb = make_uint2(0u, 0u);
     typedef __attribute__((address_space(3))) const double lds_cdouble;
     const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
@@ -813,7 +590,7 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
         if (i < nb) {
             {
                 const int ie = i + PF_E - 1, jf = i + PF_F - 1;
-                ev[ie % PF_E] = ld_d<COH>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
+                ev[ie % PF_E] = Pw[(ie < nb ? ie : nb - 1) * 64 + ulane];
                 const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
                 fb[jf % PF_F] = fro[ulane];
                 fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
@@ -860,12 +637,8 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
         }
     }
     {
-        // the same bits, one byte per pair, for the panel role (a 64-bit agent-scope store in the one-launch form)
-        const uint2 sp = spread2(fresh);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rSn + ulane);
-        const unsigned long long val = (unsigned long long)sp.x | ((unsigned long long)sp.y << 32);
-        if (COH) __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = val;
+        // the same bits, one byte per pair, for the panel role
+        rSn[ulane] = spread2(fresh);
     }
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
@@ -876,7 +649,6 @@ __device__ __forceinline__ bool r_role_diag(const r_step_args &a, int b, int u, 
     }
     __builtin_amdgcn_s_setprio(0);
     FCD_TRACE(trec, 3);
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1398,22 +1170,6 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_pipe_kernel(const r_step_ar
                 return;
             }
         }
-        if (a.xcd) {
-            // (knob r_xcd) Workgroups are dealt to the 8 XCDs round-robin by block index; give each XCD a CONTIGUOUS piece of
-            // the (chunk, row) list, so that the 16 rows of a chunk -- which all read that chunk's r bytes -- sit on one
-            // XCD (two at a piece boundary) and its L2 holds them once instead of eight times.  A heuristic about
-            // placement only: every (chunk, row) is still served exactly once.
-            auto upto = [](int n, int r) { return n <= 0 ? 0 : (n + 7 - r) >> 3; };            // block indices < n with residue r
-            auto panel_before = [&](int n, int r) {                                           // ... that are panel workgroups
-                int c = upto(n, r) - upto(a.nD < n ? a.nD : n, r);
-                if (a.npad) c -= upto(n < a.ncu + a.npad ? n : a.ncu + a.npad, r) - upto(n < a.ncu ? n : a.ncu, r);
-                return c;
-            };
-            const int x = blk & 7, end = a.nD + a.nP + a.npad;
-            int start = 0;
-            for (int y = 0; y < x; ++y) start += panel_before(end, y);
-            item = start + panel_before(blk, x);
-        }
         const int row = item % R_NB, uc = item / R_NB;
         for (int wg = 0; wg < a.nWG; ++wg) pipe_panel<UB>(a, row, uc, wg, smem, err);
     }
@@ -1430,7 +1186,7 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int blk = blockIdx.x;
     if (blk < a.nD) {
-        r_role_diag<false>(a, a.s - 1, a.u_lo + blk % a.u_n, blk / a.u_n, smem, nullptr, 0u, nullptr, nullptr);
+        r_role_diag(a, a.s - 1, a.u_lo + blk % a.u_n, blk / a.u_n, smem);
     } else {
         int item = blk - a.nD;
         if (a.npad) {
@@ -1442,217 +1198,7 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_step_kernel(const r_step_ar
         }
         const int rows = (a.Nreg - a.s * R_NB < R_NB) ? (a.Nreg - a.s * R_NB) : R_NB;
         const int nUC = (a.u_n + UB - 1) / UB;
-        // (knob r_stagger, for launches of several rounds of workgroups: the second workgroup of every CU starts late, so
-        // that the two of a CU -- and the ones that follow them -- are not in the same phase at the same time)
-        if (a.stagger > 0 && blk >= a.ncu && blk < 2 * a.ncu)
-            for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-        r_role_panel<UB, false>(a, a.s, item % rows, (item / rows) % nUC, item / (rows * nUC), smem, nullptr, 0u, nullptr, nullptr);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One-launch form of the same pass.  grid = U + 16 * ceil(U / UB) workgroups, ALL resident at once (the host
-// checks the occupancy): workgroup (u) walks D(0), D(1), ... of its patient, workgroup (row, uc) walks P(0), P(1), ...
-// of its region-of-the-block and patient chunk; groups of chain words one after the other.  The steps of a patient
-// chunk hand over through two counters per (word group, chunk, step):
-//   cntP: panel workgroups of the step that are done   -> D(s) of the chunk's patients may start at rows(s)
-//   cntD: D workgroups of the chunk that finished block s -> P(s+2) of the chunk may start at nu(chunk)
-// Every wait is on work of an earlier step of workgroups that are already running, so the scan cannot stall; the
-// chunks are independent pipelines and drift apart, which keeps the LDS busy while others stage or wait.  No kernel
-// boundary (~5 us each on this part) between the steps.
-// ---------------------------------------------------------------------------------------------
-template <int UB, int WPE>
-__global__ __launch_bounds__(1024, WPE) void gibbs_r_pass_kernel(const r_step_args a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int sh_ok;
-    const int nUC = (a.U + UB - 1) / UB;
-    const int NB = a.NBLK;
-    uint32_t *cntP = a.flags, *cntD = a.flags + (size_t)a.nWG * nUC * NB, *err = a.flags + (size_t)2 * a.nWG * nUC * NB;
-    const int blk = blockIdx.x;
-    if (blk < a.U) {
-        const int u = blk, uc = u / UB;
-        for (int wg = 0; wg < a.nWG; ++wg) {
-            for (int b = 0; b < NB; ++b) {
-                const int rows = (a.Nreg - b * R_NB < R_NB) ? (a.Nreg - b * R_NB) : R_NB;
-                const size_t fi = ((size_t)wg * nUC + uc) * NB + b;
-                if (!r_role_diag<true>(a, b, u, wg, smem, cntP + fi, (uint32_t)rows, err, &sh_ok)) return;
-                r_signal(cntD + fi);
-            }
-        }
-    } else {
-        const int item = blk - a.U;
-        const int row = item % R_NB, uc = item / R_NB;
-        const int nu = (a.U - uc * UB < UB) ? (a.U - uc * UB) : UB;
-        for (int wg = 0; wg < a.nWG; ++wg) {
-            for (int st = 0; st < NB; ++st) {
-                const int rows = (a.Nreg - st * R_NB < R_NB) ? (a.Nreg - st * R_NB) : R_NB;
-                if (row >= rows) continue;
-                const size_t fi = ((size_t)wg * nUC + uc) * NB + st;
-                const uint32_t *wf = st >= 2 ? cntD + fi - 2 : nullptr;
-                if (!r_role_panel<UB, true>(a, st, row, uc, wg, smem, wf, (uint32_t)nu, err, &sh_ok)) return;
-                r_signal(cntP + fi);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ROW-SEQUENTIAL r pass (alternative, FCD_R_PATH=1; same chains bit for bit): ONE launch walks all regions in order.
-//
-// grid = (U, ceil(GW / WB)); block = 16 waves = WB chain words x MS "splits" (WB = 16 / MS).  Wave (word, s) owns the
-// regions m = s, s+MS, s+2MS, ...: it keeps their r bits of its 64 chains in ONE register (bit j <-> m = s + MS j),
-// and per region n gets the f codes of its edges (n, m) as one packed word (f2, made by pack_f2_kernel).
-// Per region n (a step):
-//   all waves   sum their terms  lMd[u][n][m][f_c][r_m]  from the LDS row of n (staged one step ahead, double buffer),
-//               put the partial sums in LDS, and meet at ONE barrier;
-//   owner wave  (s = n mod MS, the one whose register holds r_n) then adds the MS partials, compares with the
-//               precomputed threshold logit(x) (r_thr_all_kernel), flips its own bit, and publishes the 64 chains'
-//               r_n as a ballot -- while the other waves are already in step n+1 (they never need r_n).
-// No partial-sum buffer in HBM, no diagonal kernels, 3 launches per pass instead of 28.
-// ---------------------------------------------------------------------------------------------
-template <int MS>
-__global__ __launch_bounds__(256) void pack_f2_kernel(const uint8_t *__restrict__ f_state, int Nreg, int GW, int C32, int mode,
-                                                      uint64_t *__restrict__ f2) {
-    const int lane = threadIdx.x & 63;
-    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));       // (w, n, s)
-    if (item >= GW * Nreg * MS) return;
-    const int s = item % MS, n = (item / MS) % Nreg, w = item / (MS * Nreg);
-    const uint8_t *__restrict__ fw = f_state + (int64_t)w * C32 * 64 + lane;
-    uint64_t v = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-        const int m = s + MS * j;
-        if (m < Nreg && m != n) v |= (uint64_t)fw[(int64_t)fcd_pair_to_edge(n, m, mode) * 64] << (2 * j);
-    }
-    f2[(int64_t)item * 64 + lane] = v;
-}
-
-// thr[((w*U + u)*Nreg + n)][lane] for every region: one wave per (w, pair of patients, region) = one counter block
-__global__ __launch_bounds__(256) void r_thr_all_kernel(double *__restrict__ thr, int Nreg, int U, int GW, uint32_t chain0,
-                                                        uint64_t seed, uint32_t sweep) {
-    const int lane = threadIdx.x & 63;
-    const int U2 = (U + 1) / 2;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (int64_t)GW * U2 * Nreg) return;
-    const int n = (int)(item % Nreg);
-    const int64_t wq = item / Nreg;
-    const int uq = (int)(wq % U2), w = (int)(wq / U2);
-    const fcd_u4 x = fcd_philox((uint32_t)(n * U2 + uq), chain0 + (uint32_t)w * 64u + lane, sweep, FCD_KIND_R, (uint32_t)seed,
-                                (uint32_t)(seed >> 32));
-    double *o = thr + (((int64_t)w * U + 2 * uq) * Nreg + n) * 64 + lane;
-    o[0] = fcd_logit(fcd_u53(x.x, x.y));
-    if (2 * uq + 1 < U) o[(int64_t)Nreg * 64] = fcd_logit(fcd_u53(x.z, x.w));
-}
-
-template <int MS>
-__global__ __launch_bounds__(1024) void gibbs_r_seq_kernel(const double *__restrict__ lMd, const double *__restrict__ hyper,
-                                                           const uint64_t *__restrict__ f2, const double *__restrict__ thr,
-                                                           uint64_t *__restrict__ r_bits, int Nreg, int U, int GW) {
-    constexpr int WB = 16 / MS;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int row_dbl = Nreg * 6;
-    double *rows = smem;                                   // [2][Nreg*6]
-    double *part = smem + 2 * row_dbl;                     // [2][WB][MS][64]
-    const int u = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int jw = wave / MS, s = wave % MS;
-    const int w = blockIdx.y * WB + jw;
-    const bool live = w < GW;
-    const int njs = (Nreg - s + MS - 1) / MS;              // regions owned by this split
-    const int64_t wu = (int64_t)(live ? w : 0) * U + u;
-    uint64_t *__restrict__ rcol = r_bits + (int64_t)(live ? w : 0) * Nreg * U + u;
-
-    uint32_t rw = 0;                                       // bit j = r of region s + MS j for this lane's chain
-    if (live) {
-        for (int j = 0; j < njs; ++j) rw |= (uint32_t)((rcol[(int64_t)(s + MS * j) * U] >> lane) & 1ull) << j;
-    }
-    const int row_d2 = Nreg * 3;
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(lMd + ((int64_t)u * Nreg + 0) * row_dbl);
-        double2 *dst = reinterpret_cast<double2 *>(rows);
-        for (int i = threadIdx.x; i < row_d2; i += blockDim.x) dst[i] = src[i];
-    }
-    const uint64_t *__restrict__ f2w = f2 + ((int64_t)(live ? w : 0) * Nreg * MS + s) * 64 + lane;   // + n*MS*64
-    const double *__restrict__ thw = thr + (wu * Nreg) * 64 + lane;                                   // + n*64
-    const double dpi = hyper[FCD_H_LNPI1] - hyper[FCD_H_LNPI0];
-    const bool t0 = (int)threadIdx.x < row_d2, t1 = (int)threadIdx.x + 1024 < row_d2;
-    auto row_src = [&](int n) { return reinterpret_cast<const double2 *>(lMd + ((int64_t)u * Nreg + n) * row_dbl); };
-
-    // Latency plan (a step is ~1 us, an L2/HBM round trip about as much): the row of region n+1 is written to LDS at
-    // step n from registers that were loaded at step n-2; f words are fetched four steps at a time one group ahead;
-    // the owner fetches its next threshold MS steps ahead.
-    double2 pa0 = make_double2(0.0, 0.0), pa1 = pa0, pb0 = pa0, pb1 = pa0;     // rows in flight: (even, odd) issue steps
-    if (Nreg > 1) { if (t0) pa0 = row_src(1)[threadIdx.x]; if (t1) pa1 = row_src(1)[threadIdx.x + 1024]; }
-    if (Nreg > 2) { if (t0) pb0 = row_src(2)[threadIdx.x]; if (t1) pb1 = row_src(2)[threadIdx.x + 1024]; }
-    uint64_t fq[4], fn[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        fq[q] = (live && q < Nreg) ? f2w[(int64_t)q * MS * 64] : 0ull;
-        fn[q] = (live && 4 + q < Nreg) ? f2w[(int64_t)(4 + q) * MS * 64] : 0ull;
-    }
-    double tcur = (live && s < Nreg) ? thw[(int64_t)s * 64] : 0.0;      // threshold of this wave's first own region n = s
-    __syncthreads();
-
-    // one region; p0/p1 hold row n+1 (loaded two steps ago) and are re-armed with row n+3
-    auto step = [&](int n, double2 &p0, double2 &p1, uint64_t fcur) {
-        const int cur = n & 1;
-        // this wave's terms of row n:  m = s + MS j  ->  record at (s + MS j) * 48 bytes; f picks +16 k, r picks +8 t
-        const char *rb = reinterpret_cast<const char *>(rows + cur * row_dbl) + s * 48;
-        double d0 = 0.0, d1 = 0.0;
-        const uint32_t flo = (uint32_t)fcur, fhi = (uint32_t)(fcur >> 32);
-        auto off = [&](uint32_t fword, int jf, int jr) -> uint32_t {
-            return (((fword >> (2 * jf)) & 3u) << 4) | (((rw >> jr) & 1u) << 3);
-        };
-        int j = 0;
-        for (; j + 4 <= njs && j < 16; j += 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = *reinterpret_cast<const double *>(rb + off(flo, j + q, j + q) + (uint32_t)((j + q) * MS * 48));
-                if (q & 1) d1 += v; else d0 += v;
-            }
-        }
-        for (; j < njs && j < 16; ++j) d0 += *reinterpret_cast<const double *>(rb + off(flo, j, j) + (uint32_t)(j * MS * 48));
-        for (; j < njs; ++j)        // regions 16.. of this split: codes in the high word
-            d1 += *reinterpret_cast<const double *>(rb + off(fhi, j - 16, j) + (uint32_t)(j * MS * 48));
-        part[((cur * WB + jw) * MS + s) * 64 + lane] = d0 + d1;
-        if (n + 1 < Nreg) {
-            double2 *dst = reinterpret_cast<double2 *>(rows + (cur ^ 1) * row_dbl);
-            if (t0) dst[threadIdx.x] = p0;
-            if (t1) dst[threadIdx.x + 1024] = p1;
-        }
-        if (n + 3 < Nreg) {
-            if (t0) p0 = row_src(n + 3)[threadIdx.x];
-            if (t1) p1 = row_src(n + 3)[threadIdx.x + 1024];
-        }
-        // Barrier for LDS only.  __syncthreads() carries a workgroup fence that also drains every global load and
-        // store in flight (vmcnt(0)) -- i.e. the prefetches above -- on each of the Nreg steps.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (live && (n % MS) == s) {
-            // owner of region n: all partial sums, the draw, its own bit, the 64 chains' r_n as one word
-            const double *pp = part + ((cur * WB + jw) * MS) * 64 + lane;
-            double sum = 0.0;
-#pragma unroll
-            for (int q = 0; q < MS; ++q) sum += pp[q * 64];
-            const uint32_t t = tcur < (dpi + sum) ? 1u : 0u;
-            const int jn = n / MS;
-            rw = (rw & ~(1u << jn)) | (t << jn);
-            const uint64_t ball = __ballot(t);
-            if (lane == 0) rcol[(int64_t)n * U] = ball;
-            if (n + MS < Nreg) tcur = thw[(int64_t)(n + MS) * 64];
-        }
-    };
-
-    for (int n = 0; n < Nreg; n += 4) {
-        step(n, pa0, pa1, fq[0]);
-        if (n + 1 < Nreg) step(n + 1, pb0, pb1, fq[1]);
-        if (n + 2 < Nreg) step(n + 2, pa0, pa1, fq[2]);
-        if (n + 3 < Nreg) step(n + 3, pb0, pb1, fq[3]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            fq[q] = fn[q];
-            fn[q] = (live && n + 8 + q < Nreg) ? f2w[(int64_t)(n + 8 + q) * MS * 64] : 0ull;
-        }
+        r_role_panel<UB>(a, a.s, item % rows, (item / rows) % nUC, item / (rows * nUC), smem);
     }
 }
 
@@ -1728,25 +1274,6 @@ int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s,
     return FCD_OK;
 }
 
-template <int UB, int WPE>
-int launch_pass(fcd_ctx *ctx, const r_step_args &a, size_t shmem, int grid, bool *fits, hipStream_t s) {
-    const void *fn = reinterpret_cast<const void *>(&gibbs_r_pass_kernel<UB, WPE>);
-    {
-        int rc = fcd_lds_attr(ctx, FCD_KA_R_PASS + (UB == 4 ? 2 : UB - 1), fn, shmem);
-        if (rc) return rc;
-    }
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * a.wpb, shmem);
-    if (e != hipSuccess) return (int)e;
-    *fits = (int64_t)per_cu * ctx->num_cu >= grid;      // every workgroup resident at once, or no one-launch form
-    if (!*fits) return FCD_OK;
-    fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
-    hipLaunchKernelGGL((gibbs_r_pass_kernel<UB, WPE>), dim3((unsigned)grid), dim3(64 * a.wpb), shmem, s, a);
-    fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
-    FCD_LAUNCH_CHECK();
-    return FCD_OK;
-}
-
 // pipelined one-launch form: *fits = every workgroup resident at once (the occupancy is asked for once per shape)
 template <int UB, int WPE>
 int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bool launch, hipStream_t s) {
@@ -1786,23 +1313,16 @@ static r_ws_layout r_ws_blocked(int64_t Nreg, int64_t U, int64_t GW) {
     L.t_bytes = (size_t)GW * U * R_NB * 64 * sizeof(double);        // one buffer of panel values
     L.f_bytes = (size_t)GW * Nreg * NBLK * 64 * sizeof(uint2);
     L.s_bytes = (size_t)GW * U * NBLK * 64 * sizeof(uint2);
-    const int64_t nWGs = (GW + 15) / 16;
-    // one-launch form: counters of (at most U) chunks + its error word; pipelined form: one mark per (word, patient, block)
-    L.flag_words = (size_t)2 * nWGs * U * NBLK + 1 + (size_t)GW * U * NBLK;
+    L.flag_words = (size_t)GW * U * NBLK;                           // pipelined form: one mark per (word, patient, block)
     L.total = 2 * L.t_bytes + L.f_bytes + 2 * L.s_bytes + L.flag_words * sizeof(uint32_t) + 512;
     return L;
 }
-static size_t r_ws_seq(int64_t Nreg, int64_t U, int64_t GW) {
-    const int MSsel = (Nreg <= 256) ? 8 : 16;
-    return (size_t)GW * Nreg * MSsel * 64 * sizeof(uint64_t) + (size_t)GW * U * Nreg * 64 * sizeof(double) + 512;
-}
-
 }  // namespace
 
 size_t fcd_r_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW, int r_path) {
     const size_t per_u_need = (size_t)((Nreg + R_NB - 1) / R_NB) * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
     if (per_u_need > 156 * 1024 || Nreg + U > 65535) return 0;          // generic kernel: no scratch
-    return r_path == 1 ? r_ws_seq(Nreg, U, GW) : r_ws_blocked(Nreg, U, GW).total;
+    return r_ws_blocked(Nreg, U, GW).total;
 }
 
 extern "C" int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMd,
@@ -1823,35 +1343,14 @@ extern "C" int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t N
     return FCD_OK;
 }
 
-extern "C" int fcd_gibbs_pair_table_bytes(int64_t Nreg, int64_t U, size_t *bytes) {
-    if (Nreg < 2 || U < 1 || !bytes) return FCD_ERR_ARG;
-    *bytes = (size_t)U * Nreg * ((Nreg + R_NB - 1) / R_NB * (R_NB / 2)) * 36 * sizeof(double);
-    return FCD_OK;
-}
-
-extern "C" int fcd_gibbs_region_pair_tables(fcd_ctx *ctx, const double *lMd, int64_t Nreg, int64_t U, double *lMp,
-                                            fcd_stream stream) {
-    if (!ctx || !lMd || !lMp) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_gibbs_region_pair_tables: null pointer");
-    if (Nreg < 2 || U < 1) return fcd_fail(ctx, FCD_ERR_SHAPE, "need Nreg >= 2 and U >= 1 (Nreg=%lld, U=%lld)", Nreg, U);
-    const int64_t NP = (Nreg + R_NB - 1) / R_NB * (R_NB / 2);
-    const int64_t total = U * Nreg * NP * 9;
-    int64_t blocks = (total + 255) / 256;
-    const int64_t cap = (int64_t)ctx->num_cu * 16;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(region_pair_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lMd, (int)Nreg, (int)U,
-                       (int)NP, lMp);
-    FCD_LAUNCH_CHECK();
-    return FCD_OK;
-}
-
-extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                                 const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                                 int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream) {
-    return fcd_gibbs_r_step_sq(ctx, lM, lMd, lMp, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, edge_mode,
+    return fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep, edge_mode,
                                (hipStream_t)stream, nullptr);
 }
 
-int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq) {
     fcd_geo g;
@@ -1873,50 +1372,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         hipLaunchKernelGGL(gibbs_r_simple, dim3((unsigned)U, (unsigned)g.GW), dim3(64 * R_WAVES), shmem, s, lM, hyper, f_state,
                            r_bits, (int)Nreg, (int)U, g.C, (uint32_t)chain0, seed, (uint32_t)sweep, edge_mode);
         FCD_LAUNCH_CHECK();
+        ctx->r_form_last = 0;
         return FCD_OK;
     }
-    // ---- row-sequential path: Nreg <= 32 regions per split with 8 or 16 splits, rows of <= 2048 double2 ----
-    {
-        // 0 (default): blocked panel/diagonal kernels; 1: row-sequential kernel.  Measured at cfg3: 0.59 ms vs 0.81 ms --
-        // the row-sequential form pays ~10 VALU instructions per term (the blocked panel ~2 per region, thanks to pair
-        // records and f/r words shared by the patients of a workgroup) and leaves CUs unevenly loaded (400 workgroups).
-        const int path = ctx->knobs.r_path;
-        const int MSsel = (Nreg <= 256) ? 8 : 16;
-        const size_t seq_lds = ((size_t)2 * Nreg * 6 + (size_t)2 * 16 * 64) * sizeof(double);
-        if (path == 1 && Nreg <= 32 * MSsel && Nreg * 3 <= 2048 && seq_lds <= 64 * 1024 &&
-            (int64_t)g.GW * Nreg * MSsel < INT32_MAX / 4 && g.C * 64 <= INT32_MAX) {
-            const size_t f2_bytes = (size_t)g.GW * Nreg * MSsel * 64 * sizeof(uint64_t);
-            rc = fcd_ws_reserve(ctx, r_ws_seq(Nreg, U, g.GW));
-            if (rc) return rc;
-            uint64_t *f2 = (uint64_t *)ctx->ws;
-            double *thr_all = (double *)((char *)ctx->ws + f2_bytes);
-            const int64_t items_f = (int64_t)g.GW * Nreg * MSsel;
-            if (MSsel == 8)
-                hipLaunchKernelGGL(pack_f2_kernel<8>, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, g.GW,
-                                   (int)g.C, edge_mode, f2);
-            else
-                hipLaunchKernelGGL(pack_f2_kernel<16>, dim3((unsigned)((items_f + 3) / 4)), dim3(256), 0, s, f_state, (int)Nreg, g.GW,
-                                   (int)g.C, edge_mode, f2);
-            FCD_LAUNCH_CHECK();
-            const int64_t items_t = (int64_t)g.GW * ((U + 1) / 2) * Nreg;
-            hipLaunchKernelGGL(r_thr_all_kernel, dim3((unsigned)((items_t + 3) / 4)), dim3(256), 0, s, thr_all, (int)Nreg, (int)U, g.GW,
-                               (uint32_t)chain0, seed, (uint32_t)sweep);
-            FCD_LAUNCH_CHECK();
-            const int WB = 16 / MSsel;
-            dim3 grid((unsigned)U, (unsigned)((g.GW + WB - 1) / WB));
-            fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
-            if (MSsel == 8)
-                hipLaunchKernelGGL(gibbs_r_seq_kernel<8>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
-                                   (int)U, g.GW);
-            else
-                hipLaunchKernelGGL(gibbs_r_seq_kernel<16>, grid, dim3(1024), seq_lds, s, lMd, hyper, f2, thr_all, r_bits, (int)Nreg,
-                                   (int)U, g.GW);
-            fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
-            FCD_LAUNCH_CHECK();
-            return FCD_OK;
-        }
-    }
-    // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | flags
+    // blocked path.  Workspace: P[2] | f_S | r_S | r_Sn | marks
     const int NBLK = (int)((Nreg + R_NB - 1) / R_NB);
     const r_ws_layout L = r_ws_blocked(Nreg, U, g.GW);
     const size_t t_bytes = L.t_bytes, f_bytes = L.f_bytes, s_bytes = L.s_bytes;
@@ -1931,7 +1390,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     wsp += f_bytes;
     uint2 *r_S = (uint2 *)wsp, *r_Sn = (uint2 *)(wsp + s_bytes);
     wsp += 2 * s_bytes;
-    uint32_t *flags = (uint32_t *)wsp;
+    uint32_t *marks = (uint32_t *)wsp;
     fcd_abl_refresh(s);
     // patients per panel workgroup: the pair tile (288 B per pair of regions) + the single rows must fit the LDS
     const size_t per_u = (size_t)NBLK * ((R_NB / 2) * 36 + R_NB * 6) * sizeof(double);
@@ -1951,7 +1410,6 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     r_step_args a;
     a.lMd = lMd; a.hyper = hyper; a.f_S = f_S;
     a.r_S = r_S; a.r_Sn = r_Sn; a.r_bits = r_bits;
-    a.lMp = ctx->knobs.r_nopre ? nullptr : lMp;      // (knob r_nopre: build the records in LDS although the table is there)
     a.Pbuf[0] = Pb[0]; a.Pbuf[1] = Pb[1];
     a.flags = nullptr;
     a.Nreg = (int)Nreg; a.U = (int)U; a.NBLK = NBLK; a.GW = g.GW;
@@ -1961,22 +1419,17 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     a.s = 0; a.nD = 0; a.nP = 0;
     a.ncu = ctx->num_cu; a.npad = 0;
     a.chain0 = (uint32_t)chain0; a.sweep = (uint32_t)sweep; a.seed = seed;
-    a.prefetch = ctx->knobs.r_prefetch;
-    a.direct = ctx->knobs.r_direct;
-    a.stagger = ctx->knobs.r_stagger;
-    a.xcd = ctx->knobs.r_xcd;
     a.tol = 16.0 * FCD_LOGIT_FAST_ERR;
     a.poll_limit = ctx->knobs.r_poll_limit > 0 ? ctx->knobs.r_poll_limit : R_POLL_LIMIT;
     a.withhold = ctx->knobs.r_withhold;
     if (ctx->knobs.r_tol > a.tol) a.tol = ctx->knobs.r_tol;   // test hook: a huge value sends every draw through the exact path
     const int nUC = (int)((U + ub - 1) / ub);
-    const int persist = ctx->knobs.r_persist;     // EXPERIMENTAL one-launch form (slower)
     // Pipelined one-launch form (the default where it fits; knob r_path = 3 keeps the step-per-launch form): needs every
-    // workgroup resident at once and the pinned error word.
+    // workgroup resident at once (with a few slots to spare) and the pinned error word.
     bool pipe = false;
     r_pipe_init pinit;
     pinit.marks = nullptr; pinit.P[0] = pinit.P[1] = nullptr;
-    if ((ctx->knobs.r_path == 0 || ctx->knobs.r_path == 2) && ctx->dev_err && !persist && ctx->knobs.r_streams != 2) {
+    if (ctx->knobs.r_path != 3 && ctx->dev_err) {
         a.nD = (int)U;
         a.nP = R_NB * nUC;
         a.npad = (!ctx->knobs.r_nopad && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
@@ -1985,8 +1438,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, false, s);
         if (rc) return rc;
         if (pipe) {
-            // the marks sit behind the one-launch form's counters
-            pinit.marks = flags + ((size_t)2 * a.nWG * U * NBLK + 1);
+            pinit.marks = marks;
             pinit.P[0] = Pb[0];
             pinit.P[1] = Pb[1];
         }
@@ -2005,7 +1457,7 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
-    ctx->r_form_last = pipe ? 2 : (persist ? 3 : 1);
+    ctx->r_form_last = pipe ? 2 : 1;
     if (pipe) {
         a.flags = pinit.marks;
         if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, true, s);
@@ -2013,64 +1465,18 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, true, s);
         return rc;
     }
-    a.nD = 0; a.nP = 0; a.npad = 0;
-    // FCD_R_PERSIST=1: one launch for the whole pass, if all its workgroups fit the device at once.  Off by default:
-    // measured 348 us against 301 us for the step-per-launch form at cfg3 (a panel workgroup walks its steps back to
-    // back and the two of a CU stay in phase, so staging / pair build / terms do not overlap any better, and the
-    // hand-over adds waits), see DESIGN.md.
-    if (persist) {
-        const int grid = (int)U + R_NB * nUC;
-        bool fits = false;
-        a.flags = flags;
-        FCD_HIP_TRY(hipMemsetAsync(flags, 0, ((size_t)2 * a.nWG * nUC * NBLK + 1) * sizeof(uint32_t), s));
-        if (ub == 4) rc = launch_pass<4, 4>(ctx, a, shmem, grid, &fits, s);
-        else if (ub == 2) rc = launch_pass<2, 8>(ctx, a, shmem, grid, &fits, s);
-        else rc = launch_pass<1, 8>(ctx, a, shmem, grid, &fits, s);
-        if (rc) return rc;
-        if (fits) {
-            // the error word comes back with the stream; it is looked at by the next call on this context
-            FCD_HIP_TRY(hipMemcpyAsync((void *)ctx->dev_err, flags + (size_t)2 * a.nWG * nUC * NBLK, sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, s));
-            return FCD_OK;
-        }
-        a.flags = nullptr;
-    }
-    // Patients are independent given f, so the pass may run as TWO half-passes (patients [0, U0) and [U0, U)) on two
-    // streams: each half is its own chain of step launches, nothing crosses between them, and the tail of one half's
-    // launch (CUs left with one or no workgroup) fills with the other half's next launch instead of idling until the
-    // boundary.  One fork and one join per pass (knob r_streams = 2; U0 a multiple of 2 ub so that Philox blocks and
-    // panel chunks stay whole).
-    int n_half = 1, U0 = (int)U;
-    if (ctx->knobs.r_streams == 2 && ctx->side_stream && U >= 4 * ub) {
-        n_half = 2;
-        U0 = (int)(U / 2) / (2 * ub) * (2 * ub);
-        if (U0 < 2 * ub) U0 = 2 * ub;
-    }
-    hipStream_t hs[2] = {s, n_half == 2 ? (hipStream_t)ctx->side_stream : s};
-    if (n_half == 2) {
-        FCD_HIP_TRY(hipEventRecord((hipEvent_t)ctx->ev_fork, s));
-        FCD_HIP_TRY(hipStreamWaitEvent(hs[1], (hipEvent_t)ctx->ev_fork, 0));
-    }
+    // one launch per block step: launch st = D(st-1) workgroups + P(st) workgroups
     for (int st = 0; st <= NBLK; ++st) {
         const int rows = st < NBLK ? (int)((Nreg - (int64_t)st * R_NB < R_NB) ? (Nreg - (int64_t)st * R_NB) : R_NB) : 0;
-        for (int h = 0; h < n_half; ++h) {
-            a.u_lo = h == 0 ? 0 : U0;
-            a.u_n = n_half == 1 ? (int)U : (h == 0 ? U0 : (int)U - U0);
-            const int nUCh = (a.u_n + ub - 1) / ub;
-            a.s = st;
-            a.nD = st >= 1 ? a.u_n * a.nWG : 0;
-            a.nP = rows * nUCh * a.nWG;
-            a.npad = (!ctx->knobs.r_nopad && n_half == 1 && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
-            if (a.nD + a.nP == 0) continue;
-            if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, hs[h], h == 0);
-            else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, hs[h], h == 0);
-            else rc = launch_step<1, 8>(ctx, a, shmem, hs[h], h == 0);
-            if (rc) return rc;
-        }
-    }
-    if (n_half == 2) {
-        FCD_HIP_TRY(hipEventRecord((hipEvent_t)ctx->ev_join, hs[1]));
-        FCD_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)ctx->ev_join, 0));
+        a.s = st;
+        a.nD = st >= 1 ? (int)U * a.nWG : 0;
+        a.nP = rows * nUC * a.nWG;
+        a.npad = (!ctx->knobs.r_nopad && a.nD > 0 && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+        if (a.nD + a.nP == 0) continue;
+        if (ub == 4) rc = launch_step<4, 4>(ctx, a, shmem, s, true);
+        else if (ub == 2) rc = launch_step<2, 8>(ctx, a, shmem, s, true);
+        else rc = launch_step<1, 8>(ctx, a, shmem, s, true);
+        if (rc) return rc;
     }
     return FCD_OK;
 }

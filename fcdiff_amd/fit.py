@@ -290,10 +290,14 @@ class UnsharedRegionFit(object):
 
     @staticmethod
     def _data_digest(a):
-        flat = a.reshape(-1)
-        step = max(1, flat.shape[0] // 4096)
-        sample = flat[::step]
-        return (float(sample.sum()), float(np.abs(sample).sum()), float(flat[-1]) if flat.shape[0] else 0.0)
+        """
+        Digest of the WHOLE array (CRC-32 of its bytes: milliseconds at cfg3, next to a table build that streams the same
+        bytes): the reference re-reads self.b / self.bt on every _update_lps (fcdiff/fit.py:111-115), so any in-place
+        edit -- a single element, one patient's column -- must reach the device copy.  (A strided sample of the
+        array, as in round 2, missed whole columns: ADVICE round 2.)
+        """
+        import zlib
+        return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
 
     def invalidate_data(self):
         """Forget the device copies of b / bt: the next _update_lps() uploads them again (after in-place edits)."""

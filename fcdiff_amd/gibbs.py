@@ -55,13 +55,8 @@ class GibbsEngine(object):
     """
 
     def __init__(self, S_B, lM, Nreg, U, n_chains, chain0=0, seed=0, edge_index="symmetric", ctx=None,
-                 region_major=True, pair_table=False):
-        """
-        region_major=False keeps only lM: the generic f / r kernels run (any shape, several times slower).
-        pair_table=True also makes the pair-record table of the r pass (0.3 GB at cfg3, 5.8 GB at cfg5): tiles are then
-        copied from it instead of being built in LDS at every block step.  Off by default: measured 5 % (cfg3) and 8 %
-        (cfg5) slower per block step -- the three times larger stream costs more than the build it saves.
-        """
+                 region_major=True):
+        """region_major=False keeps only lM: the generic f / r kernels run (any shape, several times slower)."""
         import torch
         self.torch = torch
         self.ctx = ctx if ctx is not None else _lib.Context()
@@ -82,13 +77,10 @@ class GibbsEngine(object):
         self.cnt_r = torch.zeros((self.Nreg, self.U), dtype=torch.int32, device=dev)
         self.n_accumulated = 0
         self.ctx.call("fcd_ctx_reserve", self.Nreg, self.U, self.G)
-        self.lMd = self.lMf = self.lMp = None
+        self.lMd = self.lMf = None
         if region_major:
             self.lMd = torch.empty((self.U, self.Nreg, self.Nreg, 3, 2), dtype=torch.float64, device=dev)
             self.lMf = torch.empty((self.C, self.U, 3, 2), dtype=torch.float64, device=dev)
-            if pair_table:
-                n_pairs = (self.Nreg + 15) // 16 * 8
-                self.lMp = torch.empty((self.U, self.Nreg, n_pairs, 9, 4), dtype=torch.float64, device=dev)
             self.refresh_tables()
 
     def refresh_tables(self):
@@ -98,9 +90,6 @@ class GibbsEngine(object):
                           _lib.dptr(self.lMd), _lib.stream_ptr())
             self.ctx.call("fcd_gibbs_edge_tables", _lib.dptr(self.lM), self.Nreg, self.U, _lib.dptr(self.lMf),
                           _lib.stream_ptr())
-            if self.lMp is not None:
-                self.ctx.call("fcd_gibbs_region_pair_tables", _lib.dptr(self.lMd), self.Nreg, self.U, _lib.dptr(self.lMp),
-                              _lib.stream_ptr())
 
     # ---- hyper-parameters ----
     def set_hyper(self, gamma, pi2):
@@ -150,14 +139,14 @@ class GibbsEngine(object):
                       C.c_uint64(self.seed), int(sweep), _lib.stream_ptr())
 
     def r_step(self, sweep):
-        self.ctx.call("fcd_gibbs_r_step", _lib.dptr(self.lM), _lib.dptr(self.lMd), _lib.dptr(self.lMp), _lib.dptr(self.hyper),
+        self.ctx.call("fcd_gibbs_r_step", _lib.dptr(self.lM), _lib.dptr(self.lMd), _lib.dptr(self.hyper),
                       _lib.dptr(self.f_state),
                       _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0, C.c_uint64(self.seed),
                       int(sweep), self.edge_mode, _lib.stream_ptr())
 
     def sweeps(self, sweep0, n_sweeps, with_counts=False):
         self.ctx.call("fcd_gibbs_sweeps", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMf), _lib.dptr(self.lMd),
-                      _lib.dptr(self.lMp), _lib.dptr(self.hyper),
+                      _lib.dptr(self.hyper),
                       _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G, self.chain0,
                       C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode,
                       _lib.dptr(self.counts if with_counts else None), _lib.stream_ptr())
@@ -172,7 +161,7 @@ class GibbsEngine(object):
         """
         acc = accumulate_from is not None
         self.ctx.call("fcd_gibbs_run", _lib.dptr(self.S_B), _lib.dptr(self.lM), _lib.dptr(self.lMf), _lib.dptr(self.lMd),
-                      _lib.dptr(self.lMp), _lib.dptr(self.hyper), _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
+                      _lib.dptr(self.hyper), _lib.dptr(self.f_state), _lib.dptr(self.r_bits), self.Nreg, self.U, self.G,
                       self.chain0, C.c_uint64(self.seed), int(sweep0), int(n_sweeps), self.edge_mode, int(mstep_every),
                       int(accumulate_from) if acc else 0, _lib.dptr(self.counts if want_counts else None),
                       _lib.dptr(self.cnt_f if acc else None), _lib.dptr(self.cnt_r if acc else None), _lib.stream_ptr())

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FCD_ABI_VERSION 2
+#define FCD_ABI_VERSION 3
 
 #define FCD_OK 0
 #define FCD_ERR_ARG (-1)         /* null pointer / non-positive size */
@@ -73,26 +73,20 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 /* Sizes every scratch buffer of the sweep at this shape (f / r pass workspace, square f copy): after it no
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
-/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_PERSIST, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL,
- * FCD_F_FORM, FCD_R_STREAMS, read once by fcd_ctx_create; 0 = default everywhere):
+/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
+ * FCD_R_POLL_LIMIT, FCD_R_WITHHOLD, read once by fcd_ctx_create; 0 = default everywhere):
  *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
  *                  kernel boundaries) wherever every workgroup is resident at once, else one launch per block step;
- *               1: row-sequential single-launch r pass (alternative, slower); 2: as 0; 3: one launch per block step always
+ *               3: one launch per block step always
  *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
- *   "r_persist" 1: EXPERIMENTAL one-launch form of the blocked r pass (slower; device-side hand-over)
- *   "r_nopad"   1: no empty workgroups beside the in-order workgroups of a step launch
+ *   "r_nopad"   1: no empty workgroups beside the in-order workgroups
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
- *   "r_nopre"   1: ignore the pair-record table lMp (build the records in LDS at every block step)
- *   "r_direct"  1: panel records built straight from the table rows (rejected: slower; kept for the record)
- *   "r_prefetch" 1: panel workgroups touch the table rows of the next block step (no gain; kept for the record)
- *   "r_stagger" k: step form, the second panel workgroup of every CU starts k x 3.5 us late; "r_xcd" 1: pipelined form,
- *               contiguous pieces of the (chunk, row) list per XCD (both measured: no gain; kept for the record)
- *   "r_streams" 2: the blocked r pass as two half-passes over the patients on two streams (one fork / join per pass)
- *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form;
- *               4: records for triples of patients (U <= 72)
+ *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
  *   "r_poll_limit", "r_withhold"  TEST HOOKS of the pipelined r pass: bound every device-side poll by this many polls /
  *               the in-order role never announces a block (a panel wave then gives its wait up, fcd_ctx_check reports it)
- * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py). */
+ * None of them changes a result: every combination walks the same chains (tests/test_gpu_parity.py).
+ * (Round 2 carried eight more forms behind knobs -- a one-launch form with counters, a row-sequential kernel, two-stream
+ * half-passes, a pair-record table, triple records in the f pass, ... -- all measured slower; DESIGN.md keeps the numbers.) */
 int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value);
 /* Counters of the context: "n_alloc" device allocations made so far, "ws_bytes", "fsq_bytes"; "r_form_last" = the form
  * the last blocked r pass ran in (1 one launch per block step, 2 pipelined one-launch form, 3 one-launch form with
@@ -218,26 +212,18 @@ int fcd_gibbs_f_step(fcd_ctx *ctx, const double *S_B, const double *lM, const do
  * ordered-pair edge id of `edge_mode` (zeros at m == n).  Built once per table build; 48*U*Nreg*Nreg bytes. */
 int fcd_gibbs_region_tables(fcd_ctx *ctx, const double *lM, int64_t Nreg, int64_t U, int edge_mode, double *lMd,
                             fcd_stream stream);
-/* Optional PAIR-RECORD table for the r step, made from lMd (once per table build): lMp (U, Nreg, NP, 9, 4), NP = 8 ceil(Nreg/16),
- *   lMp[u][n][p][3k + k'][t + 2t'] = lMd[u][n][2p][k][t] + lMd[u][n][2p+1][k'][t']     (zero beyond Nreg)
- * -- the records the blocked r pass otherwise builds in LDS at every block step (same additions, same bits).  Passing it
- * to the r step (lMp != NULL) replaces the staging of single rows and the build by one copy of the tile; it costs
- * 288 * U * Nreg * NP bytes (fcd_gibbs_pair_table_bytes: 0.30 GB at cfg3, 5.8 GB at cfg5) and three times the table
- * traffic per pass. */
-int fcd_gibbs_pair_table_bytes(int64_t Nreg, int64_t U, size_t *bytes);
-int fcd_gibbs_region_pair_tables(fcd_ctx *ctx, const double *lMd, int64_t Nreg, int64_t U, double *lMp, fcd_stream stream);
 /* Redraw every r_nu of every chain given f, regions in order 0..Nreg-1 (systematic scan; patients
  * and chains in parallel).  With lMd (made with the SAME edge_mode) the blocked path runs: panel kernels
  * stream lMd rows through LDS, small diagonal kernels resolve the in-order dependence (only s1 - s0
  * is formed, as a sum of table differences: same conditional, one add per term).  lMd == NULL
  * selects the generic kernel that gathers from lM directly (any shape, much slower). */
-int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *lMp, const double *hyper,
+int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                      const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                      int64_t chain0, uint64_t seed, int64_t sweep, int edge_mode, fcd_stream stream);
 /* n_sweeps x (f step, r step), sweeps numbered sweep0, sweep0+1, ...  When counts != NULL the pooled
  * statistics of the LAST sweep are stored there (see fcd_gibbs_stats). */
 int fcd_gibbs_sweeps(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
-                     const double *lMp, const double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
+                     const double *hyper, uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                      uint64_t seed, int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t *counts,
                      fcd_stream stream);
 /* Pooled sufficient statistics over the G chains (the all-reduce payload):
@@ -265,8 +251,9 @@ int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits
  *       call fcd_gibbs_mstep),
  *     - makes the packed r words of the next f pass.
  *   counts (nullable) receives the pooled statistics of the LAST sweep.
- * ceil(Nreg/16) + 4 launches per sweep at the shapes the pair-form f kernel and the blocked r pass cover. */
-int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd, const double *lMp,
+ * 4 launches per sweep (f pass, packing, pipelined r pass, tally) where the pipelined r pass fits the device at once, else
+ * ceil(Nreg/16) + 4 (one launch per block step). */
+int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
                   double *hyper,
                   uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed,
                   int64_t sweep0, int64_t n_sweeps, int edge_mode, int64_t mstep_every, int64_t accumulate_from,

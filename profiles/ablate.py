@@ -35,8 +35,7 @@ def main():
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
     cases = [("f full", "f", {}), ("f no-draw", "f", {"FCD_ABL_F": "2"}), ("f staging-only", "f", {"FCD_ABL_F": "3"}),
-             ("r full", "r", {}), ("r full, one-launch form", "r", {"r_persist": 1}), ("r full, one patient per panel workgroup", "r", {"r_ub": 1}), ("r full, no empty workgroups beside D", "r", {"r_nopad": 1}),
-             ("r full, pair-record table", "r", {"r_nopre": 0}), ("r panel empty, pair-record table", "r", {"r_nopre": 0, "FCD_ABL_PANEL": "5"}),
+             ("r full", "r", {}), ("r full, one patient per panel workgroup", "r", {"r_ub": 1}), ("r full, no empty workgroups beside D", "r", {"r_nopad": 1}),
              ("r panel loads-only", "r", {"FCD_ABL_PANEL": "2"}), ("r panel staging-only", "r", {"FCD_ABL_PANEL": "3"}),
              ("r panel single rows only", "r", {"FCD_ABL_PANEL": "4"}), ("r panel empty", "r", {"FCD_ABL_PANEL": "5"}),
              ("r diag no next-thresholds", "r", {"FCD_ABL_DIAG": "1"}), ("r diag empty", "r", {"FCD_ABL_DIAG": "5"}),
@@ -48,7 +47,7 @@ def main():
         for (name, which, env) in cases:
             for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG"):
                 os.environ.pop(k, None)
-            knobs = {"r_persist": 0, "r_ub": 0, "r_nopad": 0, "r_nopre": 1, "r_path": 3}     # (fcd_ctx_set_knob; step-per-launch form)
+            knobs = {"r_ub": 0, "r_nopad": 0, "r_path": 3}     # (fcd_ctx_set_knob; step-per-launch form)
             knobs.update({k: v for (k, v) in env.items() if not k.startswith("FCD_")})
             for (k, v) in knobs.items():
                 eng.ctx.set_knob(k, v)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-Which strand bounds the pipelined r pass (knob r_path=2) at cfg3?  (diagnostic; needs `make -C fcdiff_amd/csrc ABLATE=1`)
+Which strand bounds the pipelined r pass (the default form) at cfg3?  (diagnostic; needs `make -C fcdiff_amd/csrc ABLATE=1`)
 
     FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so python profiles/ablate_pipe.py
 
@@ -33,10 +33,10 @@ def main():
     for s in range(3):
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
-    cases = [("step-per-launch form, full", {"r_path": 3}), ("pipelined, full", {"r_path": 2}),
-             ("pipelined, no panel terms", {"r_path": 2, "FCD_ABL_PANEL": "2"}),
-             ("pipelined, no in-order terms", {"r_path": 2, "FCD_ABL_DIAG": "2"}),
-             ("pipelined, neither", {"r_path": 2, "FCD_ABL_PANEL": "2", "FCD_ABL_DIAG": "2"})]
+    cases = [("step-per-launch form, full", {"r_path": 3}), ("pipelined, full", {"r_path": 0}),
+             ("pipelined, no panel terms", {"r_path": 0, "FCD_ABL_PANEL": "2"}),
+             ("pipelined, no in-order terms", {"r_path": 0, "FCD_ABL_DIAG": "2"}),
+             ("pipelined, neither", {"r_path": 0, "FCD_ABL_PANEL": "2", "FCD_ABL_DIAG": "2"})]
     res = {name: [] for (name, _) in cases}
     for rnd in range(5):
         for (name, env) in cases:

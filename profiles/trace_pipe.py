@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-Timeline of one pipelined r pass (knob r_path=2) at cfg3 (diagnostic; needs `make -C fcdiff_amd/csrc ABLATE=1`).
+Timeline of one pipelined r pass (the default form) at cfg3 (diagnostic; needs `make -C fcdiff_amd/csrc ABLATE=1`).
 
     FCDIFF_HIP_LIB=fcdiff_amd/libfcdiff_hip_abl.so python profiles/trace_pipe.py
 
@@ -28,7 +28,7 @@ def main():
     fit._init_lps(Nreg, H, U)
     fit._update_lps()
     ctx = fit._context()
-    ctx.set_knob("r_path", 2)
+    ctx.set_knob("r_path", 0)
     eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], Nreg, U, G, seed=1, ctx=ctx)
     eng.set_hyper(model.gamma, model.pi2())
     eng.init(float(model.pi))

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(raw, name), "libfcdiff_hip.so does not export %s" % name
     lib = _lib.load()
-    assert lib.fcd_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.fcd_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_host_index_maps_match_util():

@@ -103,3 +103,11 @@ def test_data_digest_sees_in_place_edits():
     d1 = UnsharedRegionFit._data_digest(b)
     np.clip(b, 0.1, 0.4, out=b)
     assert UnsharedRegionFit._data_digest(b) != d1
+    # one patient's column replaced in place at cfg3's shape (a strided sample of the array never looked at column 3)
+    bt = rng.rand(19900, 50)
+    d2 = UnsharedRegionFit._data_digest(bt)
+    bt[:, 3] = rng.rand(19900)
+    assert UnsharedRegionFit._data_digest(bt) != d2
+    d3 = UnsharedRegionFit._data_digest(bt)
+    bt[12345, 17] += 1e-12
+    assert UnsharedRegionFit._data_digest(bt) != d3

@@ -404,91 +404,31 @@ def test_gibbs_conditionals_against_reference_pins(env, tag):
         nptest.assert_allclose(eng.logjoint().cpu().numpy(), np.full(G, g["logjoint_base"]), rtol=1e-12)
 
 
-@pytest.mark.parametrize("N,U,G,mode", [(10, 4, 64, "symmetric"), (35, 6, 130, "reference"), (200, 3, 64, "symmetric"),
-                                        (257, 2, 64, "symmetric")])
-def test_gibbs_row_sequential_r_pass(env, knobs, N, U, G, mode):
-    """The alternative single-launch r pass (knob r_path=1; 8 or 16 splits of the regions) gives the oracle's chains too."""
-    knobs(r_path=1)
-    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
-    seed = 99 + N
-    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=4, seed=seed, edge_index=mode, ctx=env.ctx)
-    eng.set_hyper(m.gamma, m.pi2())
-    eng.init(0.3)
-    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 4)
-    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    for s in range(2):
-        eng.sweeps(s, 1)
-        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 4)
-        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 4)
-    f_g, r_g = eng.export_state()
-    nptest.assert_array_equal(f_g, f_o)
-    nptest.assert_array_equal(r_g, r_o)
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("kn", [{"r_path": 3}, {"r_persist": 1}, {"r_path": 3, "r_tol": 1e30},
-                                {"r_persist": 1, "r_tol": 1e30}, {"r_path": 3, "r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
-                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"f_form": 4}, {"f_form": 4, "f_tol": 1e30},
-                                {"r_path": 3, "r_nopad": 1}, {"r_path": 3, "_pair_table": 1},
-                                {"_pair_table": 1, "r_persist": 1}, {"r_path": 3, "_pair_table": 1, "r_ub": 1},
-                                {"r_path": 3, "_pair_table": 1, "r_nopre": 1},
-                                {"r_path": 3, "r_prefetch": 1}, {"r_path": 3, "r_direct": 1}, {"r_path": 3, "r_direct": 1, "r_ub": 1},
-                                {"r_path": 3, "r_stagger": 1},
-                                {"r_path": 2}, {"r_path": 2, "r_tol": 1e30}, {"r_path": 2, "r_ub": 1}, {"r_path": 2, "r_nopad": 1},
-                                {"r_path": 2, "r_xcd": 1}],
-                         ids=["step-per-launch", "one-launch", "exact-thresholds", "one-launch-exact", "one-patient",
-                              "exact-f-draws", "any-U-f-kernel", "any-U-f-kernel-exact", "scalar-mask-f-kernel",
-                              "triple-f-kernel", "triple-f-kernel-exact", "no-pad",
-                              "pair-record-table", "pair-table-one-launch", "pair-table-one-patient", "pair-table-ignored",
-                              "prefetch-hint", "records-straight-from-table", "straight-from-table-one-patient", "staggered",
-                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad", "pipelined-xcd-pieces"])
+@pytest.mark.parametrize("kn", [{"r_path": 3}, {"r_path": 3, "r_tol": 1e30}, {"r_path": 3, "r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
+                                {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_path": 3, "r_nopad": 1},
+                                {}, {"r_tol": 1e30}, {"r_ub": 1}, {"r_nopad": 1}],
+                         ids=["step-per-launch", "exact-thresholds", "one-patient", "exact-f-draws", "any-U-f-kernel",
+                              "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
+                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
-    Both forms of the blocked r pass (one launch with device-side hand-over / one launch per block step), the
-    re-decision paths of the fast draws (r_tol / f_tol huge: every r / f draw is repeated with the exact
-    logit / exponentials), a one-patient panel, the pair records built in LDS (default) or copied from the optional
-    pair-record table, and the other forms of the f pass give the oracle's chains: several blocks of 16 regions, a
-    partial last block, odd U.  Knobs go through fcd_ctx_set_knob (nothing reads the environment).
+    Both forms of the blocked r pass (pipelined one-launch form with device-side hand-over / one launch per block step),
+    the re-decision paths of the fast draws (r_tol / f_tol huge: every r / f draw is repeated with the exact
+    logit / exponentials), a one-patient panel and the other forms of the f pass give the oracle's chains: several blocks
+    of 16 regions, a partial last block, odd U.  Knobs go through fcd_ctx_set_knob (nothing reads the environment).
     """
-    kn = dict(kn)
-    pair_table = bool(kn.pop("_pair_table", 0))
     knobs(**kn)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 5 + N
-    eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx,
-                          pair_table=pair_table)
-    eng.set_hyper(m.gamma, m.pi2())
-    eng.init(0.3)
-    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
-    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    for s in range(2):
-        eng.sweeps(s, 1)
-        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
-        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 64)
-    f_g, r_g = eng.export_state()
-    nptest.assert_array_equal(f_g, f_o)
-    nptest.assert_array_equal(r_g, r_o)
-
-
-@pytest.mark.parametrize("N,U,G,mode,ub", [(40, 9, 128, "symmetric", 0), (33, 21, 1024, "reference", 0), (70, 12, 200, "symmetric", 1),
-                                           (20, 250, 128, "symmetric", 0)])
-def test_gibbs_r_pass_on_two_streams(env, knobs, N, U, G, mode, ub):
-    """
-    Knob r_streams=2: the blocked r pass as two half-passes over the patients (odd and even splits, one- and
-    two-patient panels, U > 64) on two streams gives the oracle's chains, sweep after sweep (the fork / join keeps the
-    f pass, the packing and the tally in order with both halves).
-    """
-    knobs(r_streams=2, r_ub=ub, r_path=3)
-    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
-    seed = 17 + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
     eng.set_hyper(m.gamma, m.pi2())
     eng.init(0.3)
     f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
     lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    eng.run(0, 3, mstep_every=0)
-    for s in range(3):
+    for s in range(2):
+        eng.sweeps(s, 1)
         env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
         env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES[mode], 64)
     f_g, r_g = eng.export_state()
@@ -502,12 +442,12 @@ def test_gibbs_r_pass_on_two_streams(env, knobs, N, U, G, mode, ub):
                                            (200, 50, 1024, "symmetric", 0)])
 def test_gibbs_r_pass_pipelined(env, knobs, N, U, G, mode, ub):
     """
-    Knob r_path=2: the blocked r pass in ONE launch whose workgroups hand the redrawn bits / panel sums over through
+    The default: the blocked r pass in ONE launch whose workgroups hand the redrawn bits / panel sums over through
     marks and sentinels in device memory.  Same chains as the oracle sweep after sweep: odd U, one and two patients per
     panel workgroup, a single block, two groups of chain words, a short last block, and BASELINE cfg 3's full size
     (where the first 64 chains are compared).  The context's error word stays clear (no wait was given up).
     """
-    knobs(r_path=2, r_ub=ub)
+    knobs(r_ub=ub)
     (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + U)
     seed = 23 + N
     eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, edge_index=mode, ctx=env.ctx)
@@ -657,39 +597,6 @@ def test_gibbs_sweeps_odd_shapes(env, N, U, G, mode):
     f_g, r_g = eng.export_state()
     nptest.assert_array_equal(f_g, f_o)
     nptest.assert_array_equal(r_g, r_o)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("N,U,G", [(9, 1, 64), (9, 2, 64), (12, 3, 70), (10, 4, 64), (21, 7, 130), (14, 12, 64), (14, 13, 64),
-                                   (40, 50, 1024), (17, 64, 128), (13, 72, 64), (33, 25, 2048)])
-def test_gibbs_f_pass_triple_records(env, knobs, N, U, G):
-    """
-    Knob f_form=4: the f pass with records for TRIPLES of patients (one 16-byte LDS read per three patients) walks the
-    oracle's chains through fcd_gibbs_run (whose tally makes the 12-patients-per-word slot sources of the next pass) and
-    through the separate entry points (pack_ru_kernel): one, two and three patients, a last triple of one and two, one to
-    six slot words, cfg3's U at 1024 chains, two groups of chain words.
-    """
-    knobs(f_form=4)
-    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + 3 * U)
-    seed = 31 + N
-    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
-    for fused in (True, False):
-        eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, chain0=64, seed=seed, ctx=env.ctx)
-        eng.set_hyper(m.gamma, m.pi2())
-        eng.init(0.3)
-        f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 64)
-        if fused:
-            eng.run(0, 3, mstep_every=0)
-        else:
-            for s in range(3):
-                eng.f_step(s)
-                eng.r_step(s)
-        for s in range(3):
-            env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 64)
-            env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, env.lib.EDGE_MODES["symmetric"], 64)
-        f_g, r_g = eng.export_state()
-        nptest.assert_array_equal(f_g, f_o)
-        nptest.assert_array_equal(r_g, r_o)
 
 
 def _random_shapes(n, seed):
@@ -1003,6 +910,37 @@ def test_corr_front_end_against_numpy(env, S, N, T):
     if N > 3 and T > 2:
         z = correlations(ts[:, [0, 2]], fisher_z=True, ctx=env.ctx)
         nptest.assert_allclose(z, env.O.corr_edges(ts[:, [0, 2]], fisher_z=True), rtol=1e-10, atol=1e-13)
+
+
+def test_corr_cfg3_size(env):
+    """The bench's K_corr leg at full size (S = 100 subjects, Nreg = 200, T = 1200) against numpy.corrcoef."""
+    from fcdiff_amd.corr import correlations
+    (S, N, T) = (100, 200, 1200)
+    rs = np.random.RandomState(7)
+    ts = rs.standard_normal((S, N, T)) + 0.5 * rs.standard_normal((S, 1, T))
+    got = correlations(ts, ctx=env.ctx)
+    exp = env.O.corr_edges(ts)
+    assert got.shape == (N * (N - 1) // 2, S)
+    nptest.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+
+
+def test_corr_constant_series_gives_nan_like_numpy(env):
+    """A region whose series is constant has zero variance: numpy.corrcoef gives NaN for its edges, and so must K_corr
+    (round 2 clipped the NaN to -1 through fmin / fmax: ADVICE); every other edge is unaffected."""
+    from fcdiff_amd.corr import correlations
+    (S, N, T) = (3, 20, 50)
+    rs = np.random.RandomState(4)
+    ts = rs.standard_normal((S, N, T))
+    ts[1, 5, :] = 2.5
+    with np.errstate(invalid="ignore", divide="ignore"):
+        exp = env.O.corr_edges(ts)
+    got = correlations(ts, ctx=env.ctx)
+    assert np.isnan(exp).sum() == N - 1 and np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    nptest.assert_allclose(got[ok], exp[ok], rtol=1e-11, atol=1e-13)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        z = correlations(ts, fisher_z=True, ctx=env.ctx)
+    assert np.array_equal(np.isnan(z), np.isnan(exp))
 
 
 def test_corr_feeds_the_fitter(env):
