@@ -21,6 +21,7 @@ struct fcd_knobs {
                        // per block step; 3: one launch per block step always
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups
+    int r_dsplit;      // 1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, where there are more than 8)
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
     int r_poll_limit;  // TEST HOOK: > 0 bounds every device-side poll of the pipelined r pass by this many polls (default 2^20, ~1 s)
@@ -278,9 +279,20 @@ extern __device__ unsigned long long *fcd_trace_buf;
     do {                                                                                          \
         if (fcd_trace_buf && threadIdx.x == 0) fcd_trace_buf[(size_t)(rec) * 8 + (slot)] = (unsigned long long)(v); \
     } while (0)
+// the same from thread t0 of the workgroup
+#define FCD_TRACE_AT(t0, rec, slot)                                                               \
+    do {                                                                                          \
+        if (fcd_trace_buf && threadIdx.x == (t0)) fcd_trace_buf[(size_t)(rec) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#define FCD_TRACE_VAL_AT(t0, rec, slot, v)                                                        \
+    do {                                                                                          \
+        if (fcd_trace_buf && threadIdx.x == (t0)) fcd_trace_buf[(size_t)(rec) * 8 + (slot)] = (unsigned long long)(v); \
+    } while (0)
 #else
 #define FCD_ABL(slot, lvl) false
 #define FCD_TRACE(rec, slot) do { } while (0)
 #define FCD_TRACE_VAL(rec, slot, v) do { } while (0)
+#define FCD_TRACE_AT(t0, rec, slot) do { } while (0)
+#define FCD_TRACE_VAL_AT(t0, rec, slot, v) do { } while (0)
 static inline void fcd_abl_refresh(hipStream_t) {}
 #endif

@@ -78,6 +78,10 @@ __device__ __forceinline__ uint2 spread2(uint32_t x16) {
     hi = (hi | (hi << 6)) & 0x03030303u;
     return make_uint2(lo, hi);
 }
+// LDS address of the dynamic array: 0.  The kernels of this file declare no static LDS (r_static_lds_check asks the
+// runtime before the first launch), so the array starts the workgroup's allocation -- and a term's address is the byte
+// offset inside the record plus an immediate, with no add of a base the compiler cannot see through.
+__device__ __forceinline__ uint32_t lds_base0(const double *) { return 0u; }
 // byte p of the pair word -> byte offset inside the pair record ((q << 2 | tt) << 3)
 __device__ __forceinline__ uint32_t pair_off(uint2 z, int p) {
     const uint32_t w = p < 4 ? z.x : z.y;
@@ -239,6 +243,7 @@ struct r_step_args {
     double tol;             // |v| below this: the draw is re-decided with the exact threshold (>= FCD_LOGIT_FAST_ERR)
     int poll_limit;         // pipelined form: polls before a wait is given up (R_POLL_LIMIT; smaller only through the test hook)
     int withhold;           // TEST HOOK (knob r_withhold): the in-order role never sets its marks
+    int dsplit;             // pipelined form: two in-order workgroups per patient (8 chain words each, two CUs)
 };
 
 // agent-scope (memory-side) access to what crosses workgroups inside the pipelined launch; plain otherwise
@@ -391,7 +396,7 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int r
     // LDS byte offset of the tile: reads go through an LDS-space pointer so that (block base + pair, patient offset)
     // becomes scalar base + instruction immediate
     typedef __attribute__((address_space(3))) const double lds_cdouble;
-    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    const uint32_t pb_off = lds_base0(pairs);
     double d[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) d[u] = 0.0;
@@ -583,7 +588,7 @@ __device__ __forceinline__ void r_role_diag(const r_step_args &a, int b, int u, 
     // row to the next.
     if (!hasA) rpb = make_uint2(0u, 0u);
     typedef __attribute__((address_space(3))) const double lds_cdouble;
-    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    const uint32_t pb_off = lds_base0(pairs);
     uint32_t fresh = 0;
 #pragma unroll
     for (int i = 0; i < R_NB; ++i) {
@@ -731,7 +736,7 @@ __device__ __attribute__((noinline)) double pipe_wait_e(const double *p, int lim
 }
 __device__ __forceinline__ double pipe_poll_e(const double *p, double first, int limit, volatile unsigned *err, bool &ok) {
     double e = first;
-    if (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) {
+    if (__builtin_expect(ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull, 0)) {
         e = pipe_wait_e(p, limit, err);
         if (__ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) ok = false;
     }
@@ -774,7 +779,7 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
     }
     const int64_t redrawn = a.r_Sn - a.r_S;
     typedef __attribute__((address_space(3))) const double lds_cdouble;
-    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    const uint32_t pb_off = lds_base0(pairs);
     constexpr uint32_t REC = UB * 288u;
 
     // rows of region n for the UB patients: pieces it0 + j * blockDim of [UB][pad_d2] (clamped loads, zeros beyond Nreg)
@@ -943,7 +948,9 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
 }
 
 // In-order workgroup of the pipelined form: all blocks of patient u for the group wg of chain words.
-__device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, double *smem, volatile unsigned *err) {
+// half < 0: the workgroup scans all its chain words; else only the 8 words of that half (waves 8 half .. 8 half + 7) --
+// the patient's other workgroup, on another CU, scans the rest; every wave still helps to stage and build the tiles.
+__device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, int half, double *smem, volatile unsigned *err) {
     const int Nreg = a.Nreg, U = a.U, NBLK = a.NBLK;
     const bool compact = blockDim.x == 1024;
     double *pairs = smem;
@@ -951,21 +958,26 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
     double *sB = compact ? smem + (D_RECS_T + D_SAFE) * 36 : sA + R_NB * R_NB * 6;
     const int lane = threadIdx.x & 63;
     const uint32_t ulane = (uint32_t)lane;
-    const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
-    const bool live = w < a.GW;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = wg * a.wpb + wave;
+    const bool live = w < a.GW && (half < 0 || (wave >> 3) == half);
     const int64_t wu = (int64_t)(live ? w : 0) * U + u;
     typedef __attribute__((address_space(3))) const double lds_cdouble;
-    const uint32_t pb_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)pairs;
+    const uint32_t pb_off = lds_base0(pairs);
     bool ok = true;
+    [[maybe_unused]] const unsigned tr0 = half == 1 ? 512u : 0u;      // (diagnostic build: the thread that stamps -- a live one)
     uint2 rpb = make_uint2(0u, 0u);                       // r bytes of block b-1 as this wave redrew them
     for (int b = 0; b < NBLK; ++b) {
         const int B0 = b * R_NB;
         const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
         const bool hasA = b > 0;
+        // (block 0 has no tile A: its records are zero whatever the bytes say, so the f words of tile A are then read from
+        // the block itself -- a valid address, no branch around the load)
+        const int a_back = hasA ? 64 : 0;
         [[maybe_unused]] const int trec = b * 1024 + (int)blockIdx.x;
-        FCD_TRACE(trec, 0);
-        FCD_TRACE_VAL(trec, 6, 2);
-        FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
+        FCD_TRACE_AT(tr0, trec, 0);
+        FCD_TRACE_VAL_AT(tr0, trec, 6, 2);
+        FCD_TRACE_VAL_AT(tr0, trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
         const uint2 *__restrict__ frw = a.f_S + (((int64_t)(live ? w : 0) * Nreg + B0) * NBLK + b) * 64;
         const double *__restrict__ Pw = a.Pbuf[b & 1] + (wu * R_NB) * 64;
         // e_i are asked for PF_E - 1 rows ahead (agent-scope loads: a trip to the memory side), the f words PF_F - 1 rows
@@ -983,12 +995,12 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
         for (int i = 0; i < PF_F - 1; ++i) {
             const uint2 *fro = frw + (i < nb ? i : nb - 1) * NBLK * 64;
             fb[i] = fro[ulane];
-            fa[i] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
+            fa[i] = (fro - a_back)[ulane];
         }
 #pragma unroll
         for (int i = 0; i < PF_E - 1; ++i) ev[i] = ld_d<true>(Pw + (i < nb ? i : nb - 1) * 64 + ulane);
         __syncthreads();                                   // every wave is done with the previous block's records
-        FCD_TRACE(trec, 3);
+        FCD_TRACE_AT(tr0, trec, 3);
         {
             const double2 *rowbase = reinterpret_cast<const double2 *>(a.lMd + ((int64_t)u * Nreg + B0) * Nreg * 6) + B0 * 3;
             constexpr int TILE_D2 = R_NB * R_NB * 3;
@@ -1018,7 +1030,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
             }
         }
         __syncthreads();
-        FCD_TRACE_VAL(trec, 5, wall_clock64());
+        FCD_TRACE_VAL_AT(tr0, trec, 5, wall_clock64());
         {
             const int q = threadIdx.x % 9, step = blockDim.x / 9;
             const int k = q / 3, k2 = q - 3 * k;
@@ -1059,75 +1071,123 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
             }
         }
         __syncthreads();
-        FCD_TRACE(trec, 1);
+        FCD_TRACE_AT(tr0, trec, 1);
         if (!live) continue;
         __builtin_amdgcn_s_setprio(3);
         uint32_t fresh = 0;
+        // The scan, software-pipelined.  Of the 16 terms of row i exactly ONE needs the decision of row i - 1: pair
+        // pl = (i - 1) >> 1 of the own block (tile B).  Everything else -- e_i, tile A, the other seven pairs of tile B,
+        // summed as far as the tree (t0+t1)+(t2+t3) + (t4+t5)+(t6+t7) allows without that leaf -- is the row's EARLY part
+        // and is issued while the late term of the row BEFORE is in flight: the dependent chain of a row is one LDS
+        // read and four additions instead of the whole row.  (Same tree, same sums: additions commute.)
+        int nbv = nb;          // (nb behind an opaque copy: see the loop below)
+        auto term = [&](uint32_t zw, int p, uint32_t rbase) -> double {
+            const int sft = 8 * (p & 3);
+            const uint32_t off = sft == 0 ? (zw << 3) & 0x1F8u : (zw >> (sft - 3)) & 0x1F8u;
+            return *(lds_cdouble *)(uintptr_t)(off + rbase + (uint32_t)(p * 288));
+        };
+        auto four = [&](const uint2 &z, uint32_t rbase, int p0) -> double {
+            double t[4];
 #pragma unroll
-        for (int i = 0; i < R_NB; ++i) {
-            if (i < nb) {
-                PIPE_ROW_STAMP(0);
-                {
-                    const int ie = i + PF_E - 1, jf = i + PF_F - 1;
-                    const uint2 *fro = frw + (jf < nb ? jf : nb - 1) * NBLK * 64;
-                    fb[jf % PF_F] = fro[ulane];
-                    fa[jf % PF_F] = hasA ? (fro - 64)[ulane] : make_uint2(0u, 0u);
-                    ev[ie % PF_E] = ld_d<true>(Pw + (ie < nb ? ie : nb - 1) * 64 + ulane);
-                }
-                const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
-                // one byte per pair: (q << 2) | tt -- tile A against block b-1 (this wave's own redrawn bytes), tile B against
-                // the own block (redrawn below i, old above i; the record of (i, i) is zero)
-                const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
-                PIPE_ROW_USE(za.x ^ zb.x ^ za.y ^ zb.y);
-                PIPE_ROW_STAMP(1);
-                double v = pipe_poll_e(Pw + i * 64 + ulane, ev[i % PF_E], a.poll_limit, err, ok);
-                PIPE_ROW_USE((uint32_t)__double2hiint(v));
-                PIPE_ROW_STAMP(2);
-                if (FCD_ABL(2, 2)) {                          // (ablation: no terms -- the wait for e stays)
-                    fresh |= (v + (double)(za.x + zb.y) > 0.0 ? 1u : 0u) << i;
-                    continue;
-                }
-                // four reads at a time (same sums, same order of additions as the step-per-launch form): the registers this
-                // saves over 16 reads in flight are what lets the f words be asked for three rows ahead
-                double sa, sb;
-                {
-                    const uint32_t ra = pb_off + (uint32_t)(i * (R_NB / 2) * 288), rb = pb_off + (uint32_t)((R_NB + i) * (R_NB / 2) * 288);
-                    auto four = [&](const uint2 &z, uint32_t rbase, int p0) -> double {
-                        double t[4];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            t[p] = *(lds_cdouble *)(uintptr_t)(pair_off6(z, p0 + p) + rbase + (uint32_t)((p0 + p) * 288));
-                        return (t[0] + t[1]) + (t[2] + t[3]);
-                    };
-                    const double a0 = four(za, ra, 0);
-                    PIPE_SCHED_BARRIER();
-                    const double a1 = four(za, ra, 4);
-                    PIPE_SCHED_BARRIER();
-                    sa = a0 + a1;
-                    PIPE_ROW_USE((uint32_t)__double2hiint(sa));
-                    PIPE_ROW_STAMP(3);
-                    const double b0 = four(zb, rb, 0);
-                    PIPE_SCHED_BARRIER();
-                    const double b1 = four(zb, rb, 4);
-                    PIPE_SCHED_BARRIER();
-                    sb = b0 + b1;
-                    PIPE_ROW_USE((uint32_t)__double2hiint(sb));
-                    PIPE_ROW_STAMP(4);
-                }
-                v = (v + sa) + sb;
-                if (__ballot(fabs(v) < a.tol) != 0ull)      // too close to call with the fast threshold in e_i: the exact one
-                    v += pipe_exact_corr((uint32_t)((B0 + i) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ulane,
-                                         a.sweep, a.seed, u & 1);
-                const uint32_t t = v > 0.0 ? 1u : 0u;
-                fresh |= t << i;
-                // region i now carries its new value for the rows below: bit (i & 1) of byte i / 2
-                constexpr uint32_t one = 1u;
-                const int sh = 8 * ((i >> 1) & 3) + (i & 1);
-                if ((i >> 1) < 4) rcur.x = (rcur.x & ~(one << sh)) | (t << sh);
-                else rcur.y = (rcur.y & ~(one << sh)) | (t << sh);
-                PIPE_ROW_STAMP(5);
-                PIPE_SCHED_BARRIER();
+            for (int p = 0; p < 4; ++p) t[p] = term(p0 < 4 ? z.x : z.y, p0 + p, rbase);
+            return (t[0] + t[1]) + (t[2] + t[3]);
+        };
+        auto early = [&](int i, double &vsa, double &Qo, double &Po, double &ts, uint32_t &fwl) {
+            {   // the requests for the rows ahead
+                const int ie = i + PF_E - 1, jf = i + PF_F - 1;
+                const uint2 *fro = frw + (jf < nbv ? jf : nbv - 1) * NBLK * 64;
+                fb[jf % PF_F] = fro[ulane];
+                fa[jf % PF_F] = (fro - a_back)[ulane];
+                ev[ie % PF_E] = ld_d<true>(Pw + (ie < nbv ? ie : nbv - 1) * 64 + ulane);
             }
+            const uint2 fwa = fa[i % PF_F], fwb = fb[i % PF_F];
+            // one byte per pair: (q << 2) | tt -- tile A against block b-1 (this wave's own redrawn bytes), tile B against
+            // the own block (redrawn below i, old above i; the record of (i, i) is zero)
+            const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
+            const uint32_t ra = pb_off + (uint32_t)(i * (R_NB / 2) * 288), rb = pb_off + (uint32_t)((R_NB + i) * (R_NB / 2) * 288);
+            const int pl = i > 0 ? (i - 1) >> 1 : 0, ql = pl >> 2, hl = (pl >> 1) & 1;
+            // eight reads in flight, then seven: a wave that reads four at a time spends three quarters of a row waiting for
+            // the LDS, and there are only two to four such waves per SIMD to fill the gaps
+            double ta[8], tb[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) ta[p] = term(p < 4 ? za.x : za.y, p, ra);
+            vsa = ev[i % PF_E] + (((ta[0] + ta[1]) + (ta[2] + ta[3])) + ((ta[4] + ta[5]) + (ta[6] + ta[7])));
+            PIPE_SCHED_BARRIER();
+#pragma unroll
+            for (int p = 0; p < 8; ++p) tb[p] = p == pl ? 0.0 : term(p < 4 ? zb.x : zb.y, p, rb);
+            const int qo = 4 * (1 - ql), po = 4 * ql + 2 * (1 - hl);
+            Qo = (tb[qo] + tb[qo + 1]) + (tb[qo + 2] + tb[qo + 3]);
+            Po = tb[po] + tb[po + 1];
+            ts = tb[pl ^ 1];
+            fwl = pl < 4 ? fwb.x : fwb.y;
+        };
+        double c_vsa, c_Qo, c_Po, c_ts;
+        uint32_t c_fwl;
+        early(0, c_vsa, c_Qo, c_Po, c_ts, c_fwl);
+        // A row too close to call with the fast threshold inside e_i needs the exact one (pipe_exact_corr: a call, rare).
+        // It leaves the unrolled rows for the one call site below and comes back in at the next row: the rows themselves
+        // hold no call.
+        int i0 = 0;
+        for (;;) {
+            int stop = -1;
+            double vstop = 0.0;
+            // The rows sit in a loop now, and the compiler would lift the 32 row addresses out of it (64 registers, spilled):
+            // they are made to depend on a value it cannot see through.
+            asm volatile("" : "+s"(nbv));
+#pragma unroll
+            for (int i = 0; i < R_NB; ++i) {
+                if (i >= i0 && i < nb) {
+                    const int pl = i > 0 ? (i - 1) >> 1 : 0;
+                    // the late term: rcur now carries the decision of row i - 1
+                    const double tl = term(c_fwl | (pl < 4 ? rcur.x : rcur.y), pl, pb_off + (uint32_t)((R_NB + i) * (R_NB / 2) * 288));
+                    PIPE_SCHED_BARRIER();
+                    double n_vsa = 0.0, n_Qo = 0.0, n_Po = 0.0, n_ts = 0.0;
+                    uint32_t n_fwl = 0u;
+                    if (i + 1 < R_NB && i + 1 < nb) early(i + 1, n_vsa, n_Qo, n_Po, n_ts, n_fwl);
+                    PIPE_SCHED_BARRIER();
+                    const double v = c_vsa + (((tl + c_ts) + c_Po) + c_Qo);
+                    c_vsa = n_vsa; c_Qo = n_Qo; c_Po = n_Po; c_ts = n_ts; c_fwl = n_fwl;
+                    // not clearly one side of zero in some lane: too close to call with the fast threshold inside e_i -- or
+                    // not a number, e_i was still the sentinel when it was asked for
+                    if (__builtin_expect(__ballot(!(fabs(v) >= a.tol)) != 0ull, 0)) {
+                        stop = i;
+                        vstop = v;
+                        break;
+                    }
+                    const uint32_t t = v > 0.0 ? 1u : 0u;
+                    fresh |= t << i;
+                    // region i now carries its new value for the rows below: bit (i & 1) of byte i / 2
+                    constexpr uint32_t one = 1u;
+                    const int sh = 8 * ((i >> 1) & 3) + (i & 1);
+                    if ((i >> 1) < 4) rcur.x = (rcur.x & ~(one << sh)) | (t << sh);
+                    else rcur.y = (rcur.y & ~(one << sh)) | (t << sh);
+                    PIPE_SCHED_BARRIER();
+                }
+            }
+            if (__builtin_expect(stop < 0, 1)) break;
+            if (__ballot(vstop != vstop) != 0ull) {
+                // the panels are behind: wait for e of this row (bounded) and sum the row again, from memory, the plain way
+                // (the same tree of additions)
+                double e = ld_d<true>(Pw + stop * 64 + ulane);
+                if (ok && __ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) {
+                    e = pipe_wait_e(Pw + stop * 64 + ulane, a.poll_limit, err);
+                    if (__ballot((unsigned long long)__double_as_longlong(e) == R_SENT) != 0ull) ok = false;
+                }
+                const uint2 *fro = frw + stop * NBLK * 64;
+                const uint2 fwb = fro[ulane], fwa = (fro - a_back)[ulane];
+                const uint2 za = make_uint2(fwa.x | rpb.x, fwa.y | rpb.y), zb = make_uint2(fwb.x | rcur.x, fwb.y | rcur.y);
+                const uint32_t ra = pb_off + (uint32_t)(stop * (R_NB / 2) * 288), rb = pb_off + (uint32_t)((R_NB + stop) * (R_NB / 2) * 288);
+                vstop = (e + (four(za, ra, 0) + four(za, ra, 4))) + (four(zb, rb, 0) + four(zb, rb, 4));
+            }
+            if (__ballot(fabs(vstop) < a.tol) != 0ull)
+                vstop += pipe_exact_corr((uint32_t)((B0 + stop) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ulane,
+                                     a.sweep, a.seed, u & 1);
+            const uint32_t t = vstop > 0.0 ? 1u : 0u;
+            fresh |= t << stop;
+            const int sh = 8 * ((stop >> 1) & 3) + (stop & 1);
+            if ((stop >> 1) < 4) rcur.x = (rcur.x & ~(1u << sh)) | (t << sh);
+            else rcur.y = (rcur.y & ~(1u << sh)) | (t << sh);
+            i0 = stop + 1;
         }
 #pragma unroll
         for (int i = 0; i < R_NB; ++i) {
@@ -1140,7 +1200,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
             }
         }
         rpb = spread2(fresh);
-        FCD_TRACE(trec, 2);
+        FCD_TRACE_AT(tr0, trec, 2);
         {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.r_Sn + (wu * NBLK + b) * 64 + ulane);
             const unsigned long long val = (unsigned long long)rpb.x | ((unsigned long long)rpb.y << 32);
@@ -1148,7 +1208,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, d
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // bytes, sentinels and r_bits are out before the block is announced
         if (lane == 0 && !a.withhold) __hip_atomic_store(a.flags + wu * NBLK + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        FCD_TRACE(trec, 4);
+        FCD_TRACE_AT(tr0, trec, 4);
         __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -1160,7 +1220,9 @@ __global__ __launch_bounds__(1024, WPE) void gibbs_r_pipe_kernel(const r_step_ar
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int blk = blockIdx.x;
     if (blk < a.nD) {
-        for (int wg = 0; wg < a.nWG; ++wg) pipe_diag(a, a.u_lo + blk, wg, smem, err);
+        // (dsplit: two workgroups per patient, workgroup blk and blk + U: 8 chain words each)
+        const int half = a.dsplit ? blk / a.u_n : -1;
+        for (int wg = 0; wg < a.nWG; ++wg) pipe_diag(a, a.u_lo + (a.dsplit ? blk % a.u_n : blk), wg, half, smem, err);
     } else {
         int item = blk - a.nD;
         if (a.npad) {
@@ -1261,9 +1323,26 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
     for (int n = tid; n < Nreg; n += 64 * R_WAVES) rcol[(int64_t)n * U] = mask[n];
 }
 
+// lds_base0: the kernel must have no static LDS in front of its dynamic array
+static int r_static_lds_check(fcd_ctx *ctx, const void *fn, int *done) {
+    if (*done) return FCD_OK;
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return (int)e;
+    if (fa.sharedSizeBytes != 0) {
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r pass kernel carries %lld bytes of static LDS: its table addresses assume none",
+                        (long long)fa.sharedSizeBytes);
+    }
+    *done = 1;
+    return FCD_OK;
+}
+
 template <int UB, int WPE>
 int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s, bool prof) {
     {
+        static int lds0 = 0;
+        int rc0 = r_static_lds_check(ctx, reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), &lds0);
+        if (rc0) return rc0;
         int rc = fcd_lds_attr(ctx, FCD_KA_R_STEP + (UB == 4 ? 2 : UB - 1), reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), shmem);
         if (rc) return rc;
     }
@@ -1280,6 +1359,9 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
     const void *fn = reinterpret_cast<const void *>(&gibbs_r_pipe_kernel<UB, WPE>);
     const int slot = UB == 4 ? 2 : UB - 1;
     {
+        static int lds0 = 0;
+        int rc0 = r_static_lds_check(ctx, fn, &lds0);
+        if (rc0) return rc0;
         int rc = fcd_lds_attr(ctx, FCD_KA_R_PIPE + slot, fn, shmem);
         if (rc) return rc;
     }
@@ -1429,10 +1511,19 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
     bool pipe = false;
     r_pipe_init pinit;
     pinit.marks = nullptr; pinit.P[0] = pinit.P[1] = nullptr;
+    a.dsplit = 0;
     if (ctx->knobs.r_path != 3 && ctx->dev_err) {
         a.nD = (int)U;
         a.nP = R_NB * nUC;
         a.npad = (!ctx->knobs.r_nopad && a.nD <= a.ncu && a.nD + a.nP > a.ncu) ? a.nD : 0;
+        // The in-order role is the serial chain of the pass and bound by the vector instructions ONE CU issues for a
+        // patient's 16 chain words: with more than 8 words per group give every patient two workgroups (8 words each,
+        // on two CUs beside a panel workgroup each, instead of one workgroup beside an empty one) -- knob r_dsplit = 1 keeps one.
+        if (ctx->knobs.r_dsplit != 1 && a.wpb > 8 && 2 * a.nD <= a.ncu) {
+            a.dsplit = 1;
+            a.nD = 2 * (int)U;
+            a.npad = 0;
+        }
         if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, false, s);
         else if (ub == 2) rc = launch_pipe<2, 8>(ctx, a, shmem, &pipe, false, s);
         else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, false, s);
