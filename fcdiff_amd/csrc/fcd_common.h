@@ -266,7 +266,11 @@ static inline int fcd_geo_check(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G
 // ---------------------------------------------------------------------------------------------
 #ifdef FCD_ABLATE
 extern __device__ int fcd_abl_level[4];   // [0] f kernel, [1] panel, [2] diag, [3] row stamps of the pipelined scan
+#ifdef FCD_TRACE_ONLY     // (make ABLATE=1 TRACE_ONLY=1: the time stamps without the ablation switches -- the product's code otherwise)
+#define FCD_ABL(slot, lvl) false
+#else
 #define FCD_ABL(slot, lvl) (fcd_abl_level[slot] >= (lvl))
+#endif
 void fcd_abl_refresh(hipStream_t s);
 // Timeline of the r step kernel: record (launch, workgroup) x 8 words of the 100 MHz clock, written by thread 0
 // when FCD_TRACE_PTR names a device buffer (profiles/trace_r.py).
