@@ -98,9 +98,20 @@ static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t sh
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready);
+// The f half of the tally (pooled counts of f, marginal counters of the edges): it needs nothing of the r pass, so the r
+// pass's packing launch can carry it in extra workgroups of its own instead of the tally launch after the pass.
+struct fcd_tally_f {
+    const uint8_t *f_state;
+    int64_t C, G;
+    int GW;
+    unsigned long long *acc;           // nullable: context-owned sums, [1..3] = number of f == 0, 1, 2
+    uint32_t *cnt_f;                   // nullable
+};
+// tally_f != nullptr: asked to carry the f half; *tally_f_done says whether it did (the blocked path with a packing launch)
 int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq);
+                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq,
+                        const fcd_tally_f *tally_f = nullptr, bool *tally_f_done = nullptr);
 // bracket ONE kernel launch with events when profiling is on (no-ops otherwise)
 void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s);
 void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s);
@@ -236,6 +247,86 @@ __host__ __device__ static inline uint64_t fcd_active_mask(int w, int64_t G) {
     const int64_t rem = G - (int64_t)w * 64;
     return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
 }
+
+#ifdef __HIPCC__
+// The f half of the tally for workgroup lin of nblk (WAVES waves each): f_state is read once, 16 bytes per lane -- a wave
+// covers the 16 chain words x 64 chains of an edge with one load instruction; four edges per round, their loads issued
+// together (the pass is a few memory round trips long: what counts is the number of bytes in flight).  red: LDS,
+// [WAVES][3].  Integer sums: any order gives the same totals.
+template <int WAVES>
+__device__ __forceinline__ void fcd_tally_f_block(const fcd_tally_f &a, int lin, int nblk, unsigned long long (*red)[3]) {
+    const uint8_t *__restrict__ f_state = a.f_state;
+    uint32_t *__restrict__ cnt_f = a.cnt_f;
+    const int64_t C = a.C, G = a.G;
+    const int GW = a.GW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 3, wrow = lane >> 2;          // 16-byte piece of the 64-byte row, chain word within a group of 16
+    unsigned long long tot1 = 0, tot2 = 0, n_edges = 0;
+    constexpr int TE = 4;
+    for (int64_t c0 = ((int64_t)lin * WAVES + wave) * TE; c0 < C; c0 += (int64_t)nblk * WAVES * TE) {
+        for (int wg = 0; wg < GW; wg += 16) {
+            const int w = wg + wrow;
+            uint4 vv[TE];
+#pragma unroll
+            for (int t = 0; t < TE; ++t) {
+                const int64_t c = (c0 + t < C) ? c0 + t : C - 1;
+                vv[t] = *reinterpret_cast<const uint4 *>(f_state + ((int64_t)(w < GW ? w : 0) * C + c) * 64 + sub * 16);
+            }
+            const uint32_t act = (w < GW) ? (uint32_t)(fcd_active_mask(w, G) >> (sub * 16)) & 0xFFFFu : 0u;
+#pragma unroll
+            for (int t = 0; t < TE; ++t) {
+                uint4 v = vv[t];
+                if (act != 0xFFFFu) {   // partial (or absent) chain word: drop the bytes of chains that do not exist
+                    v.x &= (((act & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.y &= ((((act >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.z &= ((((act >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    v.w &= ((((act >> 12) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                }
+                uint32_t ones = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+                                __popc(v.w & 0x01010101u);
+                uint32_t twos = __popc((v.x >> 1) & 0x01010101u) + __popc((v.y >> 1) & 0x01010101u) +
+                                __popc((v.z >> 1) & 0x01010101u) + __popc((v.w >> 1) & 0x01010101u);
+                for (int o = 32; o > 0; o >>= 1) {
+                    ones += __shfl_xor(ones, o, 64);
+                    twos += __shfl_xor(twos, o, 64);
+                }
+                if (lane == 0 && c0 + t < C) {
+                    const int64_t c = c0 + t;
+                    if (cnt_f) {
+                        // (atomics because they do not wait for the old value to come back)
+                        atomicAdd(&cnt_f[c * 3 + 1], ones);
+                        atomicAdd(&cnt_f[c * 3 + 2], twos);
+                        if (wg == 0) atomicAdd(&cnt_f[c * 3 + 0], (uint32_t)G);
+                        atomicAdd(&cnt_f[c * 3 + 0], 0u - ones - twos);
+                    }
+                    tot1 += ones;
+                    tot2 += twos;
+                    if (wg == 0) n_edges += 1;
+                }
+            }
+        }
+    }
+    if (!a.acc) return;
+    // one set of atomics per workgroup (same-address atomics serialise): wave sums -> LDS -> threads 0..2
+    if (lane == 0) {
+        red[wave][0] = n_edges * (unsigned long long)G - tot1 - tot2;
+        red[wave][1] = tot1;
+        red[wave][2] = tot2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long t = 0;
+        for (int q = 0; q < WAVES; ++q) t += red[q][threadIdx.x];
+        if (t) {
+            // with the old value asked for, the add has been performed at the memory side once it returns (every access
+            // to acc[] is a device-scope atomic): whoever takes a ticket after this workgroup's barrier finds it there
+            const unsigned long long old = atomicAdd(&a.acc[1 + threadIdx.x], t);
+            asm volatile("" ::"v"(old));
+        }
+    }
+    __syncthreads();
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // host: shape checks shared by the sampler entry points

@@ -715,11 +715,12 @@ struct tally_args {
     uint32_t *cnt_f, *cnt_r;           // nullable (both or neither)
     double *hyper;                     // nullable: M-step target
     uint32_t *r_U;                     // nullable: slot words of the next f pass
-    int n_f_blocks;                    // blocks that read the state; the rest make r_U
+    int n_f_blocks;                    // blocks that read the f state (0: done elsewhere)
+    int n_r_blocks;                    // blocks that count the r bits (at least; the f blocks do too); the rest make r_U
 };
 
 __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
-    __shared__ unsigned long long red[16][4];
+    __shared__ unsigned long long red[16], redf[16][3];
     __shared__ int sh_last;
     const uint8_t *__restrict__ f_state = a.f_state;
     const uint64_t *__restrict__ r_bits = a.r_bits;
@@ -728,91 +729,46 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
     const int64_t C = a.C, NU = a.NU, G = a.G;
     const int GW = a.GW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & 3, wrow = lane >> 2;          // 16-byte piece of the 64-byte row, chain word within a group of 16
-    unsigned long long tot1 = 0, tot2 = 0, n_edges = 0;
-    // Four edges per round, their loads issued together: the pass is a few memory round trips long, what counts is
-    // the number of bytes in flight (one 16-byte load per lane and round left the memory side at ~1.4 TB/s).
-    constexpr int TE = 4;
-    // blocks [0, nfb): the f state and the r bits; blocks [nfb, gridDim): the slot words of the next f pass (they run
-    // beside the others on CUs of their own instead of after them)
+    // blocks [0, nfb): the f state (nfb == 0: the r pass's packing launch has seen to it) -- and the r bits; blocks
+    // [nfb, gridDim): the slot words of the next f pass (they run beside the others on CUs of their own instead of after them)
     const int nfb = a.n_f_blocks;
     const bool f_role = (int)blockIdx.x < nfb;
-    for (int64_t c0 = f_role ? ((int64_t)blockIdx.x * 16 + wave) * TE : C; c0 < C; c0 += (int64_t)nfb * 16 * TE) {
-        for (int wg = 0; wg < GW; wg += 16) {
-            const int w = wg + wrow;
-            uint4 vv[TE];
-#pragma unroll
-            for (int t = 0; t < TE; ++t) {
-                const int64_t c = (c0 + t < C) ? c0 + t : C - 1;
-                vv[t] = *reinterpret_cast<const uint4 *>(f_state + ((int64_t)(w < GW ? w : 0) * C + c) * 64 + sub * 16);
-            }
-            const uint32_t act = (w < GW) ? (uint32_t)(fcd_active_mask(w, G) >> (sub * 16)) & 0xFFFFu : 0u;
-#pragma unroll
-            for (int t = 0; t < TE; ++t) {
-                uint4 v = vv[t];
-                if (act != 0xFFFFu) {   // partial (or absent) chain word: drop the bytes of chains that do not exist
-                    v.x &= (((act & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
-                    v.y &= ((((act >> 4) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
-                    v.z &= ((((act >> 8) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
-                    v.w &= ((((act >> 12) & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu;
-                }
-                uint32_t ones = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
-                                __popc(v.w & 0x01010101u);
-                uint32_t twos = __popc((v.x >> 1) & 0x01010101u) + __popc((v.y >> 1) & 0x01010101u) +
-                                __popc((v.z >> 1) & 0x01010101u) + __popc((v.w >> 1) & 0x01010101u);
-                for (int o = 32; o > 0; o >>= 1) {
-                    ones += __shfl_xor(ones, o, 64);
-                    twos += __shfl_xor(twos, o, 64);
-                }
-                if (lane == 0 && c0 + t < C) {
-                    const int64_t c = c0 + t;
-                    if (cnt_f) {
-                        // (atomics because they do not wait for the old value to come back)
-                        atomicAdd(&cnt_f[c * 3 + 1], ones);
-                        atomicAdd(&cnt_f[c * 3 + 2], twos);
-                        if (wg == 0) atomicAdd(&cnt_f[c * 3 + 0], (uint32_t)G);
-                        atomicAdd(&cnt_f[c * 3 + 0], 0u - ones - twos);
-                    }
-                    tot1 += ones;
-                    tot2 += twos;
-                    if (wg == 0) n_edges += 1;
-                }
-            }
-        }
+    if (f_role) {
+        fcd_tally_f tf;
+        tf.f_state = f_state; tf.C = C; tf.G = G; tf.GW = GW; tf.acc = a.acc; tf.cnt_f = cnt_f;
+        fcd_tally_f_block<16>(tf, (int)blockIdx.x, nfb, redf);
     }
+    // the r bits: every block of the first max(nfb, n_r_blocks) takes its share
+    const int nrb = nfb > a.n_r_blocks ? nfb : a.n_r_blocks;
+    const bool r_role = (int)blockIdx.x < nrb;
     unsigned long long cr = 0;
-    for (int64_t i = f_role ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : NU; i < NU; i += (int64_t)nfb * blockDim.x) {
+    for (int64_t i = r_role ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : NU; i < NU; i += (int64_t)nrb * blockDim.x) {
         uint32_t sr = 0;
         for (int w = 0; w < GW; ++w) sr += __popcll(r_bits[(int64_t)w * NU + i] & fcd_active_mask(w, G));
         if (cnt_r) atomicAdd(&cnt_r[i], sr);
         cr += sr;
     }
-    if (a.r_U && !f_role) {
+    if (a.r_U && (int)blockIdx.x >= nrb) {
         // slot words of the next f pass: one wave per (w, n, word) item, as pack_ru_kernel
         const int U = a.U, NW = a.NW;
         const int items = GW * a.Nreg * NW;
-        for (int item = ((int)blockIdx.x - nfb) * 16 + wave; item < items; item += ((int)gridDim.x - nfb) * 16) {
+        for (int item = ((int)blockIdx.x - nrb) * 16 + wave; item < items; item += ((int)gridDim.x - nrb) * 16) {
             const int jw = item % NW, wn = item / NW;                   // wn = w*Nreg + n
             a.r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, lane);
         }
     }
     if (!a.acc) return;
-    // one set of atomics per BLOCK (same-address atomics serialise): wave sums -> LDS -> threads 0..3
+    // the r count: one atomic per BLOCK (same-address atomics serialise): wave sums -> LDS -> thread 0
     for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
-    if (lane == 0) {
-        red[wave][0] = cr;
-        red[wave][1] = n_edges * (unsigned long long)G - tot1 - tot2;
-        red[wave][2] = tot1;
-        red[wave][3] = tot2;
-    }
+    if (lane == 0) red[wave] = cr;
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x == 0) {
         unsigned long long t = 0;
-        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+        for (int q = 0; q < 16; ++q) t += red[q];
         if (t) {
             // with the old value asked for, the add has been performed at the memory side once it returns: the
             // barrier below then orders it before this block's ticket (every access to acc[] is a device-scope atomic)
-            const unsigned long long old = atomicAdd(&a.acc[threadIdx.x], t);
+            const unsigned long long old = atomicAdd(&a.acc[0], t);
             asm volatile("" ::"v"(old));
         }
     }
@@ -1220,7 +1176,7 @@ extern "C" int fcd_gibbs_accumulate(fcd_ctx *ctx, const uint8_t *f_state, const 
 // one launch of gibbs_tally_kernel; counts / cnt_f+cnt_r / hyper / r_U each optional
 static int launch_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G,
                         const fcd_geo &g, int64_t *counts, uint32_t *cnt_f, uint32_t *cnt_r, double *hyper, uint32_t *r_U,
-                        int ru_words, hipStream_t s) {
+                        int ru_words, hipStream_t s, bool f_done = false) {
     tally_args a;
     a.f_state = f_state; a.r_bits = r_bits;
     a.C = g.C; a.NU = Nreg * U; a.G = G;
@@ -1232,7 +1188,13 @@ static int launch_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_
     int64_t blocks = (g.C + 63) / 64;          // 16 waves x 4 edges per workgroup and round
     const int64_t cap = (int64_t)ctx->num_cu * 2;      // (8 per CU measured slower: 19.6 us against 15.6 us at cfg3)
     if (blocks > cap) blocks = cap;
-    a.n_f_blocks = (int)blocks;
+    a.n_f_blocks = f_done ? 0 : (int)blocks;
+    {   // the r bits alone: one thread per (region, patient), a few blocks
+        int64_t rb = (a.NU + 1023) / 1024;
+        if (rb > 64) rb = 64;
+        a.n_r_blocks = (int)rb;
+        if (f_done) blocks = rb;
+    }
     if (r_U) {
         int64_t ru_blocks = ((int64_t)g.GW * Nreg * a.NW + 15) / 16;
         if (ru_blocks > ctx->num_cu) ru_blocks = ctx->num_cu;
@@ -1291,17 +1253,25 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
     for (int64_t i = 0; i < n_sweeps; ++i) {
         rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready);
         if (rc) return rc;
-        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq);
-        if (rc) return rc;
         const bool last = i + 1 == n_sweeps;
         const bool do_m = mstep_every > 0 && (i + 1) % mstep_every == 0;
         const bool do_a = cnt_f && sweep0 + i >= accumulate_from;
+        // the f half of this sweep's tally rides in the r pass's packing launch (beside it, not after the pass)
+        fcd_tally_f tf;
+        tf.f_state = f_state; tf.C = g.C; tf.G = G; tf.GW = g.GW;
+        tf.acc = (do_m || (last && counts)) ? (unsigned long long *)ctx->acc : nullptr;
+        tf.cnt_f = do_a ? cnt_f : nullptr;
+        const bool want_f = tf.acc || tf.cnt_f;
+        bool f_done = false;
+        rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq,
+                                 want_f ? &tf : nullptr, &f_done);
+        if (rc) return rc;
         // the r pass's scratch is dead once its last launch is queued: the slot words of the next f pass go to its place
         uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)ctx->ws : nullptr;
         int64_t *cts = (last ? counts : nullptr);
         if (do_m || do_a || cts || r_U_next) {
             rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
-                              do_m ? hyper : nullptr, r_U_next, pl.NW, s);
+                              do_m ? hyper : nullptr, r_U_next, pl.NW, s, f_done);
             if (rc) return rc;
         }
         ru_ready = r_U_next != nullptr;

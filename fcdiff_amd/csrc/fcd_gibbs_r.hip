@@ -191,12 +191,19 @@ template <bool SQ>
 __global__ __launch_bounds__(256) void pack_f_kernel(const uint8_t *__restrict__ f_state, int Nreg, int NBLK, int C32,
                                                      int mode, uint2 *__restrict__ f_S, const uint64_t *__restrict__ r_bits,
                                                      int U, uint2 *__restrict__ r_S,
-                                                     const r_pipe_init pipe) {
+                                                     const r_pipe_init pipe, const fcd_tally_f tf) {
     constexpr int FB = SQ ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t turn[4][FB * R_NB * 64];      // one kilobyte per wave and block (square-copy form)
+    if ((int)blockIdx.y >= Nreg + U) {
+        // rows beyond the last patient: the f half of the sweep's tally (edge-major f state, nothing to do with the packing)
+        const int lin = (((int)blockIdx.y - (Nreg + U)) * (int)gridDim.z + (int)blockIdx.z) * (int)gridDim.x + (int)blockIdx.x;
+        fcd_tally_f_block<4>(tf, lin, ((int)gridDim.y - (Nreg + U)) * (int)gridDim.z * (int)gridDim.x,
+                             reinterpret_cast<unsigned long long (*)[3]>(&turn[0][0]));
+        return;
+    }
     const int b = FB * __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (b >= NBLK) return;
     const int y = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
-    __shared__ __attribute__((aligned(16))) uint8_t turn[4][FB * R_NB * 64];      // one kilobyte per wave and block (square-copy form)
     if (y < Nreg) pack_f_item<SQ>(f_state, Nreg, NBLK, C32, mode, f_S, (int)blockIdx.z, y, b, lane, turn[threadIdx.x >> 6]);
     else {
 #pragma unroll
@@ -1434,7 +1441,9 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
 
 int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq) {
+                        uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq,
+                        const fcd_tally_f *tally_f, bool *tally_f_done) {
+    if (tally_f_done) *tally_f_done = false;
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -1538,13 +1547,31 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         // one launch packs the f words of every region and the r words of every patient
         const int fb = fsq ? 2 : 1;                 // blocks per wave (pack_f_kernel)
         dim3 pgrid((unsigned)(((NBLK + fb - 1) / fb + 3) / 4), (unsigned)(Nreg + U), (unsigned)g.GW);
+        // ... and, asked to, the f half of the sweep's tally in extra rows of workgroups (about two per CU: four waves each,
+        // four edges per wave and round)
+        fcd_tally_f tf;
+        tf.f_state = nullptr; tf.C = 0; tf.G = 0; tf.GW = 0; tf.acc = nullptr; tf.cnt_f = nullptr;
+        if (tally_f) {
+            tf = *tally_f;
+            const int64_t per_row = (int64_t)pgrid.x * pgrid.z;
+            int64_t want = (g.C + 15) / 16;                       // workgroups of one round
+            if (want > 2 * (int64_t)ctx->num_cu) want = 2 * (int64_t)ctx->num_cu;
+            int64_t ty = (want + per_row - 1) / per_row;
+            if (ty < 1) ty = 1;
+            if (pgrid.y + ty <= 65535) {
+                pgrid.y += (unsigned)ty;
+                if (tally_f_done) *tally_f_done = true;
+            } else {
+                tf.f_state = nullptr;
+            }
+        }
         fcd_prof_begin(ctx, FCD_PROF_PACK, s);
         if (fsq)
             hipLaunchKernelGGL(pack_f_kernel<true>, pgrid, dim3(256), 0, s, fsq, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S, r_bits,
-                               (int)U, r_S, pinit);
+                               (int)U, r_S, pinit, tf);
         else
             hipLaunchKernelGGL(pack_f_kernel<false>, pgrid, dim3(256), 0, s, f_state, (int)Nreg, NBLK, (int)g.C, edge_mode, f_S,
-                               r_bits, (int)U, r_S, pinit);
+                               r_bits, (int)U, r_S, pinit, tf);
         fcd_prof_end(ctx, FCD_PROF_PACK, s);
         FCD_LAUNCH_CHECK();
     }
