@@ -75,6 +75,21 @@ static inline int fcd_fail(fcd_ctx *ctx, int code, const char *fmt, long long a 
     return code;
 }
 
+// A kernel whose table addresses assume that its dynamic LDS array starts at address 0 must declare no static LDS:
+// asked of the runtime once per kernel (*done)
+static inline int fcd_static_lds_check(fcd_ctx *ctx, const void *fn, int *done) {
+    if (*done) return FCD_OK;
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return (int)e;
+    if (fa.sharedSizeBytes != 0) {
+        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "kernel carries %lld bytes of static LDS: its table addresses assume none",
+                        (long long)fa.sharedSizeBytes);
+    }
+    *done = 1;
+    return FCD_OK;
+}
+
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
 // square copy of the f state (see fcd_gibbs_sweeps): grown like the workspace
 int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes);

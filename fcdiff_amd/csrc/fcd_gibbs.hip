@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                     v.y += v1.y;
                 }
             }
-            dst[ep * 16 + slot] = v;
+            dst[(pr * FP_EC + e) * 16 + slot] = v;       // [pair][edge][slot]: see the reads below
         }
     }
     __syncthreads();
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
     typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
     typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
-    const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ptile;   // 256-aligned
+    // The records lie [pair][edge][slot] from LDS address 0 (the kernel declares no static LDS: the host asks the runtime
+    // before the first launch), so with the loops over edges, groups and pairs unrolled the record's address is an
+    // IMMEDIATE of the read and a term's address costs a shift and a mask -- whatever the number of patients.
 
 #pragma unroll
     for (int e = 0; e < FP_EC; ++e) {
@@ -363,30 +365,29 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                     rmn[j] = ru[(uint32_t)((nm * NW16 + j) * 64) + ul];
                 }
             }
-            // LDS byte offset of the edge's records (scalar, a multiple of 256: the tile is 256-aligned)
-            const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 256));
             double b1 = 0.0, b2 = 0.0;
 #pragma unroll
             for (int g = 0; g < NW16; ++g) {
                 if (g < NG) {
                     const uint32_t zs = Zc[g];
-                    const uint32_t gb = tb + (uint32_t)(g * (8 * 256));
                     if (NPAIR - 8 * g >= 8) {
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
-                            // slot -> 16-byte records: byte offset = slot << 4, OR-ed into the (256-aligned) group base in
-                            // one instruction; the pair offset p * 256 is the read's immediate
-                            const uint32_t sh = (p == 0) ? (zs << 4) : (zs >> (4 * p - 4));
-                            uint32_t ad;
-                            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0xF0u), "v"(gb));   // (one SGPR per VOP3)
-                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(p * 256));
-                            b1 += v.x;
-                            b2 += v.y;
+                            // slot -> 16-byte records: byte offset = slot << 4
+                            const uint32_t ad = (p == 0) ? (zs << 4) & 0xF0u : (zs >> (4 * p - 4)) & 0xF0u;
+                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(((g * 8 + p) * FP_EC + e) * 256));
+                            if (g == 0 && p == 0) {          // (the sums start from the first term, not from 0 + the first term)
+                                b1 = v.x;
+                                b2 = v.y;
+                            } else {
+                                b1 += v.x;
+                                b2 += v.y;
+                            }
                         }
                     } else {
                         for (int p = 0; p < NPAIR - 8 * g; ++p) {
                             const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
-                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + gb + (uint32_t)(p * 256));
+                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + (uint32_t)(((g * 8 + p) * FP_EC + e) * 256));
                             b1 += v.x;
                             b2 += v.y;
                         }
@@ -1065,6 +1066,11 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     do {                                                                                                      \
         rc = fcd_lds_attr(ctx, SLOT, reinterpret_cast<const void *>(&KERN), pl.shmem);                        \
         if (rc) return rc;                                                                                    \
+        {                                                                                                     \
+            static int lds0 = 0; /* (the pair form's record addresses start at LDS address 0) */              \
+            rc = fcd_static_lds_check(ctx, reinterpret_cast<const void *>(&KERN), &lds0);                     \
+            if (rc) return rc;                                                                                \
+        }                                                                                                     \
         fcd_prof_begin(ctx, FCD_PROF_F, s);                                                                   \
         hipLaunchKernelGGL(KERN, grid, dim3(64 * wpb), pl.shmem, s, FCD_F_ARGS);                              \
         fcd_prof_end(ctx, FCD_PROF_F, s);                                                                     \

@@ -1330,25 +1330,11 @@ __global__ __launch_bounds__(64 * R_WAVES) void gibbs_r_simple(const double *__r
     for (int n = tid; n < Nreg; n += 64 * R_WAVES) rcol[(int64_t)n * U] = mask[n];
 }
 
-// lds_base0: the kernel must have no static LDS in front of its dynamic array
-static int r_static_lds_check(fcd_ctx *ctx, const void *fn, int *done) {
-    if (*done) return FCD_OK;
-    hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, fn);
-    if (e != hipSuccess) return (int)e;
-    if (fa.sharedSizeBytes != 0) {
-        return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "r pass kernel carries %lld bytes of static LDS: its table addresses assume none",
-                        (long long)fa.sharedSizeBytes);
-    }
-    *done = 1;
-    return FCD_OK;
-}
-
 template <int UB, int WPE>
 int launch_step(fcd_ctx *ctx, const r_step_args &a, size_t shmem, hipStream_t s, bool prof) {
     {
         static int lds0 = 0;
-        int rc0 = r_static_lds_check(ctx, reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), &lds0);
+        int rc0 = fcd_static_lds_check(ctx, reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), &lds0);
         if (rc0) return rc0;
         int rc = fcd_lds_attr(ctx, FCD_KA_R_STEP + (UB == 4 ? 2 : UB - 1), reinterpret_cast<const void *>(&gibbs_r_step_kernel<UB, WPE>), shmem);
         if (rc) return rc;
@@ -1367,7 +1353,7 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
     const int slot = UB == 4 ? 2 : UB - 1;
     {
         static int lds0 = 0;
-        int rc0 = r_static_lds_check(ctx, fn, &lds0);
+        int rc0 = fcd_static_lds_check(ctx, fn, &lds0);
         if (rc0) return rc0;
         int rc = fcd_lds_attr(ctx, FCD_KA_R_PIPE + slot, fn, shmem);
         if (rc) return rc;
