@@ -141,6 +141,8 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->fsq = nullptr;
     ctx->fsq_bytes = 0;
     ctx->acc = nullptr;
+    ctx->corr_tickets = nullptr;
+    ctx->corr_tickets_n = 0;
     ctx->prof_on = 0;
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         ctx->prof_ev[i] = nullptr;
@@ -158,6 +160,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
     ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
+    ctx->knobs.corr_form = (int)knob_env("FCD_CORR_FORM");
     ctx->knobs.r_poll_limit = (int)knob_env("FCD_R_POLL_LIMIT");
     ctx->knobs.r_withhold = (int)knob_env("FCD_R_WITHHOLD");
     ctx->r_form_last = 0;
@@ -202,6 +205,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     if (ctx->fsq) (void)hipFree(ctx->fsq);
     if (ctx->acc) (void)hipFree(ctx->acc);
+    if (ctx->corr_tickets) (void)hipFree(ctx->corr_tickets);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
         delete[] ctx->prof_ev[i];
@@ -234,6 +238,7 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;
     else if (!strcmp(name, "f_form")) k.f_form = (int)value;
+    else if (!strcmp(name, "corr_form")) k.corr_form = (int)value;
     else if (!strcmp(name, "r_poll_limit")) k.r_poll_limit = (int)value;
     else if (!strcmp(name, "r_withhold")) k.r_withhold = (int)value;
     else return fcd_fail(ctx, FCD_ERR_ARG, "fcd_ctx_set_knob: unknown knob");

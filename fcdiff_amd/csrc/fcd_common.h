@@ -26,12 +26,13 @@ struct fcd_knobs {
     double f_tol;      // > default: the same for the f draws
     int r_poll_limit;  // TEST HOOK: > 0 bounds every device-side poll of the pipelined r pass by this many polls (default 2^20, ~1 s)
     int r_withhold;    // TEST HOOK: 1 = the in-order role of the pipelined r pass never sets its marks (a panel wave then gives up)
+    int corr_form;     // 1: K_corr in 64 x 64 blocks with a moments pass also where the one-workgroup-per-subject kernel would run
     int f_form;        // 0: automatic; 2: the any-U pair kernel also where the U <= 64 one would run; 3: scalar-mask form
 };
 
 // kernels whose dynamic-LDS limit is raised with hipFuncSetAttribute: done once per (kernel, size) and remembered here
 enum { FCD_KA_F_GENERIC = 0, FCD_KA_F_COND, FCD_KA_F_DIFF, FCD_KA_F_PAIR, FCD_KA_F_PAIR_BIG = FCD_KA_F_PAIR + 4,
-       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PIPE = FCD_KA_R_STEP + 4, FCD_KA_N = FCD_KA_R_PIPE + 4 };
+       FCD_KA_R_STEP = FCD_KA_F_PAIR_BIG + 4, FCD_KA_R_PIPE = FCD_KA_R_STEP + 4, FCD_KA_CORR = FCD_KA_R_PIPE + 4, FCD_KA_N = FCD_KA_CORR + 1 };
 
 struct fcd_ctx {
     int device;
@@ -48,6 +49,8 @@ struct fcd_ctx {
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
+    void *corr_tickets;            // K_corr: one ticket per subject, zero between launches (the last taker resets it)
+    size_t corr_tickets_n;
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
     size_t fsq_bytes;
     // optional per-kernel timing with HIP events on the launch stream (fcd_prof_enable / fcd_prof_collect)

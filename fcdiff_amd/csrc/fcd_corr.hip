@@ -177,6 +177,213 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const double *__restrict
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (subject, slice of the time axis): the whole lower triangle of the subject's Gram matrix.
+//
+// The blocked kernel above reads every row of a subject 4 times over (64 x 64 blocks: 800 row loads for 200 regions) and
+// needs the means before it starts (a pass of its own over the input).  Here a workgroup of 16 waves stages ALL rows of
+// its subject, 16 time steps at a time, and owns all 16 x 16 tiles of the lower triangle (TPW per wave, consecutive in
+// row-major order): every input byte is loaded ONCE.  Centring is by the row's first sample x0 instead of its mean --
+//     sum (x - mx)(y - my) = sum (x - x0)(y - y0) - (sum (x - x0)) (sum (y - y0)) / T
+// -- a shift that removes the cancellation the raw second moment would have (the shifted values are of the size of the
+// deviations), so one pass gives Gram matrix and row sums; the deviations are the roots of the Gram diagonal, as in
+// numpy.corrcoef.  The time axis is cut in KS slices (S subjects alone would leave most CUs idle): each workgroup
+// writes its partial tiles, the last of a subject to finish (a ticket) adds the slices IN SLICE ORDER (same bits
+// whoever comes last), normalises and writes the subject-major row of tmp.
+// ---------------------------------------------------------------------------------------------
+template <int TPW>
+__global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *__restrict__ ts, int Nreg, int T, int64_t S, int PMAX,
+                                                                 int64_t C, int fisher_z, double *__restrict__ part,
+                                                                 unsigned *__restrict__ ticket, double *__restrict__ tmp) {
+    extern __shared__ __attribute__((aligned(16))) double csm[];
+    const int RT = (Nreg + 15) >> 4, RP = RT * 16, NT = RT * (RT + 1) / 2;
+    double *dg = csm + 2 * RP * CLD, *sums = dg + RP, *sd = sums + RP;     // (csm: panels [2][RP][CLD] first)
+    __shared__ int sh_last;
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = l & 15, kq = l >> 4;
+    // the wave's tiles (tr >= tc), wave-uniform
+    int tr[TPW], tc[TPW];
+    bool on[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = w * TPW + j;
+        on[j] = t < NT;
+        const int tt = on[j] ? t : 0;
+        int r = (int)((sqrt(8.0 * (double)tt + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > tt) --r;
+        while ((r + 1) * (r + 2) / 2 <= tt) ++r;
+        tr[j] = __builtin_amdgcn_readfirstlane(r);
+        tc[j] = __builtin_amdgcn_readfirstlane(tt - r * (r + 1) / 2);
+    }
+    // staging: piece idx = tid + 1024 i -> (row = idx / 8, 16-byte piece pp = idx % 8 of the row's 128 bytes per step)
+    constexpr int NPI = 2;                      // RP * 8 <= 2048 pieces (host: RP <= 256)
+    const int pp = tid & 7;
+    const bool even = (T & 1) == 0;
+    // workgroup -> (subject, slice ks of KS of the time axis)
+    const int KS = PMAX;
+    const int s = (int)blockIdx.x / KS, ks = (int)blockIdx.x % KS;
+    const int steps_all = (T + CK - 1) / CK, per = (steps_all + KS - 1) / KS;
+    const int st_lo = ks * per, st_hi = (st_lo + per < steps_all) ? st_lo + per : steps_all;
+    const double *xp[NPI];
+    double x0[NPI], rs[NPI];
+    bool va[NPI];
+    int prow[NPI];
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        prow[i] = (tid >> 3) + 128 * i;
+        va[i] = prow[i] < Nreg;
+        xp[i] = ts + ((int64_t)s * Nreg + (va[i] ? prow[i] : 0)) * T;
+        x0[i] = va[i] ? xp[i][0] : 0.0;
+        rs[i] = 0.0;
+    }
+    // fetch only ASKS for the step's values; they are shifted, masked and summed in put, behind the MFMAs of the step
+    // before (anything done to them in fetch would wait for the loads in front of those MFMAs)
+    double2 raw[NPI];
+    int kf = 0;
+    auto fetch = [&](int st) {
+        kf = st * CK + 2 * pp;
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            if (even) {
+                const int kc = kf < T ? kf : T - 2;            // clamped: no branch around the load
+                raw[i] = *reinterpret_cast<const double2 *>(xp[i] + kc);
+            } else {
+                const int k0c = kf < T ? kf : T - 1, k1c = kf + 1 < T ? kf + 1 : T - 1;
+                raw[i] = make_double2(xp[i][k0c], xp[i][k1c]);
+            }
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            double2 v;
+            v.x = (va[i] && kf < T) ? raw[i].x - x0[i] : 0.0;
+            v.y = (va[i] && kf + 1 < T) ? raw[i].y - x0[i] : 0.0;
+            rs[i] += v.x + v.y;
+            if (prow[i] < RP) *reinterpret_cast<double2 *>(&csm[buf * RP * CLD + prow[i] * CLD + 2 * pp]) = v;
+        }
+    };
+    double4_t acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (st_lo < st_hi) {
+        fetch(st_lo);
+        put(0);
+    }
+    __syncthreads();
+    for (int st = st_lo; st < st_hi; ++st) {
+        const int cur = (st - st_lo) & 1;
+#if !(defined(CORR_EXP) && CORR_EXP == 3)   // (timing experiment 3: one fetch, no more)
+        if (st + 1 < st_hi) fetch(st + 1);
+#endif
+        // (a slot beyond the last tile runs tile 0 again and is dropped at the end: no branch around an MFMA)
+        const double *P = csm + cur * RP * CLD + (i16 * CLD + kq);
+#pragma unroll
+        for (int g = 0; g < CK / 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+#if defined(CORR_EXP) && CORR_EXP == 2      // (timing experiment: no fragment reads)
+                const double fa = (double)(g + j), fb = (double)(kq + j);
+#else
+                const double fa = P[tr[j] * (16 * CLD) + g * 4];
+                const double fb = P[tc[j] * (16 * CLD) + g * 4];
+#endif
+#if defined(CORR_EXP) && CORR_EXP == 1      // (timing experiment: no MFMA)
+                acc[j][0] += fa * fb;
+#else
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[j], 0, 0, 0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (the fragments of one k-quarter in flight, not of all four)
+        }
+        if (st + 1 < st_hi) put(cur ^ 1);
+        __syncthreads();
+    }
+    // row sums of the slice: the 8 pieces of a row sit in 8 consecutive lanes
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        double v = rs[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if (pp == 0 && prow[i] < RP) sums[prow[i]] = v;
+    }
+    __syncthreads();
+    const int64_t psz = (int64_t)NT * 256 + RP;
+    if (KS > 1) {
+        // The slices meet in memory.  Every partial value is written and read with agent-scope accesses (straight to / from
+        // the memory side: the L2s of the XCDs are not coherent with one another), the ticket is drawn once they are
+        // acknowledged -- no fence: a device-scope fence writes back / invalidates a whole L2, and one per wave of every
+        // workgroup cost more than the Gram product itself (215 of 350 us).
+        double *mine = part + ((int64_t)s * PMAX + ks) * psz;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            if (on[j]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(mine + (int64_t)(w * TPW + j) * 256 + r * 64 + l, acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (tid < RP) __hip_atomic_store(mine + (int64_t)NT * 256 + tid, sums[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                   // (waits for every wave's stores to be acknowledged)
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&ticket[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)KS - 1u;
+            if (last) __hip_atomic_store(&ticket[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_last = last;
+        }
+        __syncthreads();
+        if (!sh_last) return;
+        // the slices in slice order
+        const double *p0 = part + (int64_t)s * PMAX * psz;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            if (!on[j]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double *q0 = p0 + (int64_t)(w * TPW + j) * 256 + r * 64 + l;
+                double a = __hip_atomic_load(q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 1; q < KS; ++q) a += __hip_atomic_load(q0 + q * psz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[j][r] = a;
+            }
+        }
+        if (tid < RP) {
+            double v = __hip_atomic_load(p0 + (int64_t)NT * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 1; q < KS; ++q) v += __hip_atomic_load(p0 + q * psz + (int64_t)NT * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sums[tid] = v;
+        }
+    }
+    // diagonal of the Gram matrix -> deviations
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (on[j] && tr[j] == tc[j]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kq + 4 * r == i16) dg[tr[j] * 16 + i16] = acc[j][r];
+        }
+    }
+    __syncthreads();
+    const double inv = 1.0 / (double)(T - 1), invT = 1.0 / (double)T;
+    if (tid < RP) sd[tid] = sqrt((dg[tid] - sums[tid] * sums[tid] * invT) * inv);      // sqrt(diag(cov))
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (!on[j]) continue;
+        const int m = tc[j] * 16 + i16;                                  // column = the smaller region index of the pair
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tr[j] * 16 + kq + 4 * r;                       // row
+            if (n < Nreg && m < n) {
+                double c = (acc[j][r] - sums[n] * sums[m] * invT) * inv;
+                c /= sd[n];
+                c /= sd[m];
+                c = (c != c) ? c : fmin(fmax(c, -1.0), 1.0);             // (a constant series: 0 / 0 = NaN like numpy.corrcoef)
+                if (fisher_z) c = atanh(c);
+                tmp[(int64_t)s * C + (fcd_tri(n) + m)] = c;              // 16 lanes = 16 consecutive edges = 128 bytes
+            }
+        }
+    }
+}
+
 // tmp (S, C) -> out (C, S): the layout of b / bt (edge-major, subjects fastest).  The Gram kernel writes subject-major
 // rows (128 contiguous bytes per 16 lanes); written straight into (C, S) every value would be an 8-byte store 8 S bytes
 // from the next one -- 40 M partial-line writes at cfg5.  32 x 32 tiles through LDS, both sides coalesced.
@@ -206,12 +413,55 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     if (S < 1 || Nreg < 2 || T < 2) return fcd_fail(ctx, FCD_ERR_SHAPE, "need S >= 1, Nreg >= 2, T >= 2 (Nreg=%lld, T=%lld)", Nreg, T);
     if (S > 65535 || Nreg > 46340 || T > INT32_MAX) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: shape too large");
     const int64_t rows = S * Nreg, C = fcd_tri(Nreg);
+    hipStream_t s = (hipStream_t)stream;
+    if ((S + 31) / 32 > 65535) return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_corr_edges: grid too large");
+    // Up to 208 regions (16 waves x 6 tiles of 16 x 16 cover the lower triangle): one workgroup per (subject, time slice)
+    constexpr int TPW = 6;
+    const int RT = (int)((Nreg + 15) / 16), RP = RT * 16, NT = RT * (RT + 1) / 2;
+    if (NT <= 16 * TPW && ctx->knobs.corr_form != 1) {
+        // slices of the time axis: about one workgroup per CU (S subjects alone would leave most CUs idle), no slice
+        // shorter than 4 steps
+        const int64_t steps_all = (T + CK - 1) / CK;
+        int64_t KS = ctx->num_cu / S;
+        if (KS > steps_all / 4) KS = steps_all / 4;
+        if (KS < 1) KS = 1;
+        if (KS > 16) KS = 16;
+        const int64_t NWG = S * KS;
+        const int PMAX = (int)KS;
+        const size_t psz = (size_t)NT * 256 + RP;
+        const size_t part_bytes = (size_t)S * PMAX * psz * sizeof(double);
+        int rc = fcd_ws_reserve(ctx, part_bytes + (size_t)S * C * sizeof(double));
+        if (rc) return rc;
+        // the tickets live in the context, zero between launches (the last taker of a subject puts its ticket back):
+        // no memset launch per call.  Growing them synchronises, like growing the scratch.
+        if (ctx->corr_tickets_n < (size_t)S) {
+            FCD_HIP_TRY(hipDeviceSynchronize());
+            if (ctx->corr_tickets) (void)hipFree(ctx->corr_tickets);
+            ctx->corr_tickets = nullptr;
+            ctx->corr_tickets_n = 0;
+            FCD_HIP_TRY(hipMalloc(&ctx->corr_tickets, (size_t)S * sizeof(unsigned)));
+            FCD_HIP_TRY(hipMemset(ctx->corr_tickets, 0, (size_t)S * sizeof(unsigned)));
+            ctx->corr_tickets_n = (size_t)S;
+        }
+        unsigned *ticket = (unsigned *)ctx->corr_tickets;
+        double *part = (double *)ctx->ws;
+        double *tmp = (double *)((char *)ctx->ws + part_bytes);
+        const size_t shmem = ((size_t)2 * RP * CLD + 3 * RP) * sizeof(double);
+        rc = fcd_lds_attr(ctx, FCD_KA_CORR, reinterpret_cast<const void *>(&corr_gram_subject_kernel<TPW>), shmem);
+        if (rc) return rc;
+        hipLaunchKernelGGL(corr_gram_subject_kernel<TPW>, dim3((unsigned)NWG), dim3(1024), shmem, s, ts, (int)Nreg, (int)T, S,
+                           PMAX, C, fisher_z ? 1 : 0, part, ticket, tmp);
+        FCD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(corr_transpose_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((S + 31) / 32)), dim3(256), 0, s, tmp, S, C, out);
+        FCD_LAUNCH_CHECK();
+        return FCD_OK;
+    }
+    // more regions: 64 x 64 blocks, the means and deviations in a pass of their own
     // workspace: means and deviations of the rows, then the subject-major copy of the result (grows the context's
     // scratch, which synchronises, the first time a shape needs it)
     int rc = fcd_ws_reserve(ctx, ((size_t)rows * 2 + (size_t)S * C) * sizeof(double));
     if (rc) return rc;
     double *mean = (double *)ctx->ws, *sdev = mean + rows, *tmp = sdev + rows;
-    hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_moments_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ts, rows, (int)T, mean, sdev);
     FCD_LAUNCH_CHECK();
     const int64_t nb = (Nreg + CB - 1) / CB;

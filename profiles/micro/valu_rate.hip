@@ -35,6 +35,9 @@ BODY(k_mullo, "v_mul_lo_u32 %0, %1, %0\n v_mul_lo_u32 %2, %3, %2")
 BODY(k_cndmask, "v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc")
 BODY(k_sdwa, "v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_or_b32_sdwa %2, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2")
 BODY(k_pkadd, "v_pk_add_f32 %4, %4, %5\n v_pk_add_f32 %5, %5, %4")
+BODY(k_fmac64, "v_fmac_f64_e32 %4, 1.0, %5\n v_fmac_f64_e32 %5, 1.0, %4")
+BODY(k_fma64, "v_fma_f64 %4, %4, 1.0, %5\n v_fma_f64 %5, %5, 1.0, %4")
+BODY(k_fmac32, "v_fmac_f32_e32 %0, 1.0, %1\n v_fmac_f32_e32 %2, 1.0, %3")
 
 int main() {
     hipDeviceProp_t p;
@@ -46,7 +49,7 @@ int main() {
         {"v_and_b32", k_and}, {"v_lshrrev_b32", k_lshr}, {"v_and_or_b32 (inline const)", k_andor}, {"v_and_b32 (literal)", k_andlit},
         {"v_add_u32", k_addu}, {"v_lshl_add_u32", k_lshladd}, {"v_bfe_u32", k_bfe}, {"v_mad_u32_u24", k_madu24}, {"v_perm_b32", k_perm},
         {"v_fma_f32", k_fma32}, {"v_add_f64", k_add64}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_lo_u32", k_mullo}, {"v_cndmask_b32", k_cndmask},
-        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}};
+        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}, {"v_fmac_f64_e32 (VOP2, x 1.0)", k_fmac64}, {"v_fma_f64 (VOP3)", k_fma64}, {"v_fmac_f32_e32", k_fmac32}};
     const int iters = 2000;
     uint64_t *h = (uint64_t *)malloc((size_t)cus * 4 * 8 * 8);
     for (auto &k : ks) {
