@@ -319,7 +319,7 @@ def main():
         ts = torch.randn((S_all, Nreg, T), dtype=torch.float64, device="cuda")
         correlations(ts, ctx=ctx, as_numpy=False)
         torch.cuda.synchronize()
-        n_rep = 5
+        n_rep = 20
         tcr = time.perf_counter()
         for _ in range(n_rep):
             correlations(ts, ctx=ctx, as_numpy=False)
@@ -328,14 +328,15 @@ def main():
         flops_full = 2.0 * S_all * Nreg * Nreg * T                       # SURVEY 8d convention (full product; SYRK does half)
         flops_syrk = 2.0 * S_all * (Nreg * (Nreg + 1) / 2) * T
         corr_bytes = 8 * S_all * Nreg * T + 8 * C * S_all
-        out["corr"] = {"kernel": "corr_gram_kernel (+ corr_moments_kernel)", "bound": "mfma", "dtype": "f64",
+        out["corr"] = {"kernel": "corr_gram_subject_kernel (+ corr_transpose_kernel)", "bound": "mfma", "dtype": "f64",
                        "workload": "S=%d subjects, Nreg=%d, T=%d" % (S_all, Nreg, T), "ms": corr_ms,
                        "flops_full_product": flops_full, "flops_lower_triangle": flops_syrk,
                        "achieved": flops_syrk / (corr_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops_syrk / (corr_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                        "hbm_GBps": corr_bytes / (corr_ms * 1e-3) / 1e9, "hbm_frac": corr_bytes / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "note": "both launches of fcd_corr_edges, wall time of %d calls; flops counted for the lower triangle "
-                               "actually needed; the input is read twice (moments, Gram)" % n_rep}
+                       "note": "both launches of fcd_corr_edges, wall time of %d calls (queue kept full: the calls are "
+                               "asynchronous); flops counted for the lower triangle actually needed; the input is read once "
+                               "(centring by the first sample, row sums beside the Gram product)" % n_rep}
         del ts
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -73,13 +73,17 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 /* Sizes every scratch buffer of the sweep at this shape (f / r pass workspace, square f copy): after it no
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
-/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
- * FCD_R_POLL_LIMIT, FCD_R_WITHHOLD, read once by fcd_ctx_create; 0 = default everywhere):
+/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
+ * FCD_CORR_FORM, FCD_R_POLL_LIMIT, FCD_R_WITHHOLD, read once by fcd_ctx_create; 0 = default everywhere):
  *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
  *                  kernel boundaries) wherever every workgroup is resident at once, else one launch per block step;
  *               3: one launch per block step always
  *   "r_ub"      1 / 2 / 4: patients per panel workgroup of the blocked r pass (0: chosen by shape)
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups
+ *   "r_dsplit"  1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, on two CUs,
+ *               where a group has more than 8 chain words and 2 U <= number of CUs)
+ *   "corr_form" 1: fcd_corr_edges in 64 x 64 blocks with a moments pass also where the one-workgroup-per-subject kernel
+ *               (up to 208 regions) would run
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)
  *   "f_form"    2: the any-U pair kernel of the f pass also where the U <= 64 kernel would run; 3: scalar-mask form
  *   "r_poll_limit", "r_withhold"  TEST HOOKS of the pipelined r pass: bound every device-side poll by this many polls /
@@ -251,7 +255,8 @@ int fcd_gibbs_tally(fcd_ctx *ctx, const uint8_t *f_state, const uint64_t *r_bits
  *       call fcd_gibbs_mstep),
  *     - makes the packed r words of the next f pass.
  *   counts (nullable) receives the pooled statistics of the LAST sweep.
- * 4 launches per sweep (f pass, packing, pipelined r pass, tally) where the pipelined r pass fits the device at once, else
+ * 4 launches per sweep (f pass; packing, which also carries the f half of the tally in workgroups of its own; pipelined r
+ * pass; the rest of the tally: r counts, slot words, M-step) where the pipelined r pass fits the device at once, else
  * ceil(Nreg/16) + 4 (one launch per block step). */
 int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *lMd,
                   double *hyper,

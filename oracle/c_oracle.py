@@ -35,12 +35,14 @@ def lib():
         L.oracle_gibbs_init.argtypes = [_pb, _pb, _i64, _i64, _i64, _i64, _u64, C.c_double]
         L.oracle_gibbs_f_step.argtypes = [_pb, _pb, _pd, _pd, _pd, _i64, _i64, _i64, _i64, _u64, _i64, C.c_void_p, _int]
         L.oracle_gibbs_r_step.argtypes = [_pb, _pb, _pd, _pd, _i64, _i64, _i64, _i64, _u64, _i64, _int, C.c_void_p, _int]
+        L.oracle_gibbs_f_step_m.argtypes = [_pb, _pb, _pd, _pd, _pd, _i64, _i64, _i64, _i64, _u64, _i64, _pd]
+        L.oracle_gibbs_r_step_m.argtypes = [_pb, _pb, _pd, _pd, _i64, _i64, _i64, _i64, _u64, _i64, _int, _pd]
         L.oracle_gibbs_stats.argtypes = [_pb, _pb, _i64, _i64, _i64, _pi]
         L.oracle_gibbs_logjoint.argtypes = [_pb, _pb, _pd, _pd, _pd, _pd, _i64, _i64, _i64, _pd]
         L.oracle_max_threads.restype = _int
         for fn in ("oracle_lik_tables", "oracle_update_lq_F", "oracle_update_lq_R", "oracle_energy_terms",
-                   "oracle_gibbs_init", "oracle_gibbs_f_step", "oracle_gibbs_r_step", "oracle_gibbs_stats",
-                   "oracle_gibbs_logjoint"):
+                   "oracle_gibbs_init", "oracle_gibbs_f_step", "oracle_gibbs_r_step", "oracle_gibbs_f_step_m",
+                   "oracle_gibbs_r_step_m", "oracle_gibbs_stats", "oracle_gibbs_logjoint"):
             getattr(L, fn).restype = None
         _lib = L
     return _lib
@@ -107,6 +109,23 @@ def gibbs_r_step(f, r, lM, lnpi2, seed, sweep, mode, chain0=0, want_cond=False, 
     lib().oracle_gibbs_r_step(f, r, _f64(lM), _f64(lnpi2), Nreg, U, G, chain0, seed, sweep, int(mode),
                               cond.ctypes.data if want_cond else None, int(draw))
     return cond
+
+
+def gibbs_f_step_margin(f, r, S_B, lM, lngamma, seed, sweep, chain0=0):
+    """gibbs_f_step, returning the smallest tie margin of its draws (distance of t = x * sum(w) to the nearer threshold,
+    relative to sum(w)): a statistic for the parity tests, not part of the algorithm."""
+    (G, Nreg, U) = r.shape
+    out = np.zeros(1)
+    lib().oracle_gibbs_f_step_m(f, r, _f64(S_B), _f64(lM), _f64(lngamma), Nreg, U, G, chain0, seed, sweep, out)
+    return float(out[0])
+
+
+def gibbs_r_step_margin(f, r, lM, lnpi2, seed, sweep, mode, chain0=0):
+    """gibbs_r_step, returning the smallest |(s1 - s0) - logit(x)| of its draws."""
+    (G, Nreg, U) = r.shape
+    out = np.zeros(1)
+    lib().oracle_gibbs_r_step_m(f, r, _f64(lM), _f64(lnpi2), Nreg, U, G, chain0, seed, sweep, int(mode), out)
+    return float(out[0])
 
 
 def gibbs_stats(f, r):

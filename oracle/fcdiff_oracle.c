@@ -240,13 +240,24 @@ static inline int draw_f(double a0, double a1, double a2, double x) {
     const double t = x * ((e0 + e1) + e2);
     return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
 }
+/* TEST STATISTIC (not part of the algorithm): how close the draw came to a tie -- the distance of t to the nearer of its
+   two thresholds, relative to the sum of the weights */
+static inline double draw_f_margin(double a0, double a1, double a2, double x) {
+    double mx = a0 > a1 ? a0 : a1;
+    mx = mx > a2 ? mx : a2;
+    const double e0 = exp(a0 - mx), e1 = exp(a1 - mx), e2 = exp(a2 - mx);
+    const double s = (e0 + e1) + e2, t = x * s;
+    const double d0 = fabs(t - e0), d1 = fabs(t - (e0 + e1));
+    return (d0 < d1 ? d0 : d1) / s;
+}
 
 /* f conditionals: fit.py:170-173 at one-hot q_R.  cond (G,C,3) optional: unnormalised log-weights. */
-void oracle_gibbs_f_step(uint8_t *f, const uint8_t *r, const double *S_B, const double *lM, const double *lngamma,
-                         int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, double *cond,
-                         int draw) {
+static void gibbs_f_step_impl(uint8_t *f, const uint8_t *r, const double *S_B, const double *lM, const double *lngamma,
+                              int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, double *cond,
+                              int draw, double *margin) {
     const int64_t C = tri(Nreg);
-#pragma omp parallel for schedule(dynamic, 1)
+    double mm = 1.0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(min : mm)
     for (int64_t g = 0; g < G; ++g) {
         const uint8_t *rg = r + g * Nreg * U;
         for (int64_t c = 0; c < C; ++c) {
@@ -263,18 +274,36 @@ void oracle_gibbs_f_step(uint8_t *f, const uint8_t *r, const double *S_B, const 
             }
             for (int k = 0; k < 3; ++k) a[k] = lngamma[k] + (S_B[c * 3 + k] + a[k]);
             if (cond) memcpy(cond + (g * C + c) * 3, a, sizeof(a));
-            if (draw)
-                f[g * C + c] = (uint8_t)draw_f(a[0], a[1], a[2], site_uniform32(seed, (uint32_t)(c >> 2), (uint32_t)(chain0 + g),
-                                                                                (uint32_t)sweep, KIND_F, (int)(c & 3)));
+            if (draw) {
+                const double x = site_uniform32(seed, (uint32_t)(c >> 2), (uint32_t)(chain0 + g), (uint32_t)sweep, KIND_F, (int)(c & 3));
+                f[g * C + c] = (uint8_t)draw_f(a[0], a[1], a[2], x);
+                if (margin) {
+                    const double d = draw_f_margin(a[0], a[1], a[2], x);
+                    if (d < mm) mm = d;
+                }
+            }
         }
     }
+    if (margin) *margin = mm;
+}
+void oracle_gibbs_f_step(uint8_t *f, const uint8_t *r, const double *S_B, const double *lM, const double *lngamma,
+                         int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, double *cond,
+                         int draw) {
+    gibbs_f_step_impl(f, r, S_B, lM, lngamma, Nreg, U, G, chain0, seed, sweep, cond, draw, NULL);
+}
+/* the same step; *margin = the smallest tie margin of its draws (draw_f_margin) -- a statistic for the parity tests */
+void oracle_gibbs_f_step_m(uint8_t *f, const uint8_t *r, const double *S_B, const double *lM, const double *lngamma,
+                           int64_t Nreg, int64_t U, int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, double *margin) {
+    gibbs_f_step_impl(f, r, S_B, lM, lngamma, Nreg, U, G, chain0, seed, sweep, NULL, 1, margin);
 }
 
 /* r conditionals: fit.py:187-194 at one-hot q_F, q_R; regions in order, state refreshed in place. */
-void oracle_gibbs_r_step(const uint8_t *f, uint8_t *r, const double *lM, const double *lnpi2, int64_t Nreg, int64_t U,
-                         int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, int mode, double *cond, int draw) {
+static void gibbs_r_step_impl(const uint8_t *f, uint8_t *r, const double *lM, const double *lnpi2, int64_t Nreg, int64_t U,
+                              int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, int mode, double *cond, int draw,
+                              double *margin) {
     const int64_t C = tri(Nreg);
-#pragma omp parallel for schedule(dynamic, 1)
+    double mm = 1e300;
+#pragma omp parallel for schedule(dynamic, 1) reduction(min : mm)
     for (int64_t g = 0; g < G; ++g) {
         const uint8_t *fg = f + g * C;
         uint8_t *rg = r + g * Nreg * U;
@@ -304,11 +333,26 @@ void oracle_gibbs_r_step(const uint8_t *f, uint8_t *r, const double *lM, const d
                     const double x = site_uniform(seed, (uint32_t)(n * ((U + 1) >> 1) + (u >> 1)), (uint32_t)(chain0 + g),
                                                   (uint32_t)sweep, KIND_R, (int)(u & 1));
                     /* r = 1 w.p. sigmoid(s1 - s0): logit(x) < s1 - s0 */
-                    rg[n * U + u] = log(x / (1.0 - x)) < (s1 - s0);
+                    const double lx = log(x / (1.0 - x));
+                    rg[n * U + u] = lx < (s1 - s0);
+                    if (margin) {       /* TEST STATISTIC: |(s1 - s0) - logit(x)|, how close the draw came to a tie */
+                        const double d = fabs((s1 - s0) - lx);
+                        if (d < mm) mm = d;
+                    }
                 }
             }
         }
     }
+    if (margin) *margin = mm;
+}
+void oracle_gibbs_r_step(const uint8_t *f, uint8_t *r, const double *lM, const double *lnpi2, int64_t Nreg, int64_t U,
+                         int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, int mode, double *cond, int draw) {
+    gibbs_r_step_impl(f, r, lM, lnpi2, Nreg, U, G, chain0, seed, sweep, mode, cond, draw, NULL);
+}
+/* the same step; *margin = the smallest |(s1 - s0) - logit(x)| of its draws -- a statistic for the parity tests */
+void oracle_gibbs_r_step_m(const uint8_t *f, uint8_t *r, const double *lM, const double *lnpi2, int64_t Nreg, int64_t U,
+                           int64_t G, int64_t chain0, uint64_t seed, int64_t sweep, int mode, double *margin) {
+    gibbs_r_step_impl(f, r, lM, lnpi2, Nreg, U, G, chain0, seed, sweep, mode, NULL, 1, margin);
 }
 
 void oracle_gibbs_stats(const uint8_t *f, const uint8_t *r, int64_t Nreg, int64_t U, int64_t G, int64_t *counts) {

@@ -52,9 +52,12 @@ def main():
             m = ((t[L, :, 6].astype(np.int64) & 255) == role) & (t[L, :, 0] > 0)
             if not m.any():
                 continue
-            x = t[L][m]
+            x = t[L][m].copy()
             st, en = us(x[:, 0]), us(x[:, 4])
             if role == 1:
+                # steps 0 and 1 poll no mark (nothing above them has been redrawn): their 'marks seen' stamp is never
+                # written -- take 'rows parked' for it (wait = 0) instead of printing the difference to an empty word
+                x[:, 3] = np.where(x[:, 3] > 0, x[:, 3], x[:, 2])
                 print("%3d   P %4d | %7.2f [%7.2f..%7.2f] | %5.2f %5.2f %5.2f %5.2f | %s | %7.2f / %7.2f" % (
                     L, m.sum(), np.median(st), st.min(), st.max(), np.median(x[:, 1] - x[:, 0]) / 100, np.median(x[:, 2] - x[:, 1]) / 100,
                     np.median(x[:, 3] - x[:, 2]) / 100, np.median(x[:, 4] - x[:, 3]) / 100, " " * 38, np.median(en), en.max()))

@@ -7,11 +7,13 @@ GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C 
 Tolerances (fp64): tables rtol 1e-12 (device exp/log are within a few ulp of libm's); quantities
 that sum over patients/edges rtol 1e-10; integer state (Gibbs chains, counts) bit-exact.
 """
+import os
+
 import numpy as np
 import numpy.testing as nptest
 import pytest
 
-from conftest import load_golden, theta_dict
+from conftest import ROOT, load_golden, theta_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -819,11 +821,28 @@ def test_gibbs_cfg3_size_properties(env):
     # oracle: all 1024 chains
     lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
     f_o, r_o = env.CO.gibbs_init(G, N, U, 0.05, seed, 0)
+    (mf, mr) = (1.0, np.inf)
     for s in range(2):
-        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s, 0)
-        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s, 1, 0)
+        mf = min(mf, env.CO.gibbs_f_step_margin(f_o, r_o, S_B, lM, lng, seed, s, 0))
+        mr = min(mr, env.CO.gibbs_r_step_margin(f_o, r_o, lM, lnpi2, seed, s, 1, 0))
     nptest.assert_array_equal(f_g, f_o)
     nptest.assert_array_equal(r_g, r_o)
+    # Tie margins of these 2 x (1024 x 19900 f draws + 1024 x 10000 r draws), from the oracle: the draw that came closest
+    # to a tie.  The HIP kernels add the same terms in another order (pairs of patients / of regions, blocks), which moves
+    # a sum by a few ulp -- about 200 terms of size <= 50: < 1e-11 absolute for the r draws, < 1e-13 relative to the sum
+    # of weights for the f draws.  A draw nearer to its threshold than that could come out differently; the closest one
+    # here is orders of magnitude away (and the fast thresholds are re-decided exactly inside 16 x 2e-5 / the f margin).
+    margins = {"f_min_rel_distance_to_threshold": mf, "r_min_abs_v": mr, "r_fast_tolerance": 16 * 2e-5,
+               "r_min_abs_v_over_fast_tolerance": mr / (16 * 2e-5), "r_sum_rounding_bound": 1e-11,
+               "r_min_abs_v_over_rounding_bound": mr / 1e-11, "f_sum_rounding_bound": 1e-13,
+               "f_min_over_rounding_bound": mf / 1e-13, "draws_f": 2 * G * (N * (N - 1) // 2), "draws_r": 2 * G * N * U}
+    print("tie margins (cfg3, 2 sweeps, 1024 chains):", margins)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "tie_margin_cfg3.json"), "w") as fh:
+            json.dump(margins, fh, indent=1)
+    assert mr > 1e-9 and mf > 1e-11
     lj = full.logjoint().cpu().numpy()
     nptest.assert_allclose(lj[:8], env.CO.gibbs_logjoint(f_g[:8].copy(), r_g[:8].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
 

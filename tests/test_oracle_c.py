@@ -59,6 +59,30 @@ def test_c_gibbs_equals_numpy_gibbs(mode):
                            O.gibbs_logjoint(f_np, r_np, S_B, lM, lng, lnpi2), rtol=1e-13)
 
 
+def test_c_tie_margin_steps_are_the_same_steps():
+    """The steps that also report the closest tie of their draws (a statistic of the GPU parity tests) draw the same states;
+    the margins are what the conditionals say they are."""
+    g = load_golden("G11_gibbs_conditionals_cfg1")
+    th = theta_dict(g["theta"])
+    S_B = g["lp_B_g_F"].sum(axis=1)
+    lM = g["lM"]
+    (Nreg, U) = g["r_state"].shape
+    lng, lnpi2 = np.log(th["gamma"]), np.log([1 - th["pi"], th["pi"]])
+    (G, seed) = (5, 77)
+    f_a, r_a = CO.gibbs_init(G, Nreg, U, 0.3, seed, 0)
+    f_b, r_b = f_a.copy(), r_a.copy()
+    for sweep in range(2):
+        CO.gibbs_f_step(f_a, r_a, S_B, lM, lng, seed, sweep, 0)
+        mf = CO.gibbs_f_step_margin(f_b, r_b, S_B, lM, lng, seed, sweep, 0)
+        nptest.assert_array_equal(f_a, f_b)
+        cond = CO.gibbs_r_step(f_a, r_a, lM, lnpi2, seed, sweep, O.EDGE_SYMMETRIC, 0, want_cond=True)
+        mr = CO.gibbs_r_step_margin(f_b, r_b, lM, lnpi2, seed, sweep, O.EDGE_SYMMETRIC, 0)
+        nptest.assert_array_equal(r_a, r_b)
+        assert 0.0 < mf <= 0.5 and 0.0 < mr < np.abs(cond[..., 1] - cond[..., 0]).max() + 50.0
+        # the r margin cannot be smaller than the distance of any draw to ITS decision: flipping needs |v| to vanish
+        assert mr < 1.0          # (5 x 24 x 6 draws: some draw lies within 1 of its threshold)
+
+
 def test_c_conditionals_match_reference_pins():
     """C conditionals against the reference's own one-hot evaluations (G11)."""
     g = load_golden("G11_gibbs_conditionals_mid")
