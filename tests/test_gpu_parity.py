@@ -409,10 +409,11 @@ def test_gibbs_conditionals_against_reference_pins(env, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kn", [{"r_path": 3}, {"r_path": 3, "r_tol": 1e30}, {"r_path": 3, "r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
                                 {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_path": 3, "r_nopad": 1},
-                                {}, {"r_tol": 1e30}, {"r_ub": 1}, {"r_nopad": 1}],
+                                {}, {"r_tol": 1e30}, {"r_ub": 1}, {"r_nopad": 1}, {"r_dsplit": 1}, {"r_dsplit": 1, "r_tol": 1e30}],
                          ids=["step-per-launch", "exact-thresholds", "one-patient", "exact-f-draws", "any-U-f-kernel",
                               "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
-                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad"])
+                              "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad",
+                              "pipelined-one-in-order-workgroup", "pipelined-one-in-order-workgroup-exact"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
@@ -941,6 +942,21 @@ def test_corr_cfg3_size(env):
     exp = env.O.corr_edges(ts)
     assert got.shape == (N * (N - 1) // 2, S)
     nptest.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+
+
+def test_corr_both_kernels(env, knobs):
+    """The one-workgroup-per-subject kernel (centring by the first sample, slices of the time axis meeting in memory) and
+    the 64 x 64 block kernel with its moments pass: both against numpy.corrcoef, odd and even T, slices of uneven length,
+    a series far from zero mean (what the shift is for), S larger than the number of CUs / 2 (one slice)."""
+    from fcdiff_amd.corr import correlations
+    rng = np.random.RandomState(12)
+    for (S, N, T) in [(7, 50, 333), (3, 200, 1200), (150, 33, 97), (2, 17, 16)]:
+        ts = rng.randn(S, N, T) + 1e3 * rng.randn(S, N, 1)
+        exp = env.O.corr_edges(ts)
+        for form in (0, 1):
+            knobs(corr_form=form)
+            got = correlations(ts, ctx=env.ctx)
+            nptest.assert_allclose(got, exp, rtol=1e-9, atol=1e-12, err_msg="form %d shape %s" % (form, (S, N, T)))
 
 
 def test_corr_constant_series_gives_nan_like_numpy(env):
