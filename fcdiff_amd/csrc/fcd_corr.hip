@@ -266,39 +266,45 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
     double4_t acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // Two panels in LDS.  Step st: one barrier (panel st % 2 is complete, nobody reads the other one any more), the
+    // fragments of the first quarter, then the 24 MFMAs of the step -- behind every MFMA the fragments of the SAME tile for
+    // the next quarter (asked for a whole turn of the wave's six tiles before they are used), and behind the first
+    // quarter the step's share of the staging: the values of step st + 1 (asked for a step ago) are shifted, summed and
+    // put into the other panel, those of step st + 2 are asked for.  All of that issues while the matrix pipe works
+    // through the MFMAs of the SIMD's four waves; only the first fragments of a step wait for the LDS.
+    double fa[TPW], fb[TPW];
+    auto frags = [&](int buf, int j, int g) {
+        // (a slot beyond the last tile runs tile 0 again and is dropped at the end: no branch around an MFMA)
+        const double *P = csm + buf * RP * CLD + (i16 * CLD + kq);
+        fa[j] = P[tr[j] * (16 * CLD) + g * 4];
+        fb[j] = P[tc[j] * (16 * CLD) + g * 4];
+    };
     if (st_lo < st_hi) {
         fetch(st_lo);
         put(0);
+        if (st_lo + 1 < st_hi) fetch(st_lo + 1);
     }
-    __syncthreads();
     for (int st = st_lo; st < st_hi; ++st) {
         const int cur = (st - st_lo) & 1;
-#if !(defined(CORR_EXP) && CORR_EXP == 3)   // (timing experiment 3: one fetch, no more)
-        if (st + 1 < st_hi) fetch(st + 1);
-#endif
-        // (a slot beyond the last tile runs tile 0 again and is dropped at the end: no branch around an MFMA)
-        const double *P = csm + cur * RP * CLD + (i16 * CLD + kq);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) frags(cur, j, 0);
 #pragma unroll
         for (int g = 0; g < CK / 4; ++g) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-#if defined(CORR_EXP) && CORR_EXP == 2      // (timing experiment: no fragment reads)
-                const double fa = (double)(g + j), fb = (double)(kq + j);
-#else
-                const double fa = P[tr[j] * (16 * CLD) + g * 4];
-                const double fb = P[tc[j] * (16 * CLD) + g * 4];
-#endif
-#if defined(CORR_EXP) && CORR_EXP == 1      // (timing experiment: no MFMA)
-                acc[j][0] += fa * fb;
-#else
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[j], 0, 0, 0);
-#endif
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[j], acc[j], 0, 0, 0);
+                if (g + 1 < CK / 4) frags(cur, j, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);          // (the fragments of one k-quarter in flight, not of all four)
+            if (g == 0 && st + 1 < st_hi) {
+                put(cur ^ 1);
+                if (st + 2 < st_hi) fetch(st + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (st + 1 < st_hi) put(cur ^ 1);
-        __syncthreads();
     }
+    __syncthreads();
     // row sums of the slice: the 8 pieces of a row sit in 8 consecutive lanes
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
@@ -363,7 +369,9 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
     }
     __syncthreads();
     const double inv = 1.0 / (double)(T - 1), invT = 1.0 / (double)T;
-    if (tid < RP) sd[tid] = sqrt((dg[tid] - sums[tid] * sums[tid] * invT) * inv);      // sqrt(diag(cov))
+    // 1 / sqrt(diag(cov)): numpy divides by the two deviations in turn; two multiplications by their reciprocals differ from
+    // that by an ulp or two (the tests allow 1e-11) and spare every lane 48 fp64 divisions at the tail of the kernel
+    if (tid < RP) sd[tid] = 1.0 / sqrt((dg[tid] - sums[tid] * sums[tid] * invT) * inv);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -374,9 +382,9 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
             const int n = tr[j] * 16 + kq + 4 * r;                       // row
             if (n < Nreg && m < n) {
                 double c = (acc[j][r] - sums[n] * sums[m] * invT) * inv;
-                c /= sd[n];
-                c /= sd[m];
-                c = (c != c) ? c : fmin(fmax(c, -1.0), 1.0);             // (a constant series: 0 / 0 = NaN like numpy.corrcoef)
+                c *= sd[n];
+                c *= sd[m];
+                c = (c != c) ? c : fmin(fmax(c, -1.0), 1.0);             // (a constant series: 0 x inf = NaN, like numpy.corrcoef's 0 / 0)
                 if (fisher_z) c = atanh(c);
                 tmp[(int64_t)s * C + (fcd_tri(n) + m)] = c;              // 16 lanes = 16 consecutive edges = 128 bytes
             }

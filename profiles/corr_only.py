@@ -13,8 +13,8 @@ from fcdiff_amd.corr import correlations  # noqa: E402
 
 
 def main():
-    (S, N, T) = (100, 200, 1200)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    (S, N, T) = (100, 200, int(sys.argv[2]) if len(sys.argv) > 2 else 1200)
     from fcdiff_amd import _lib
     ctx = _lib.Context()
     ts = torch.randn((S, N, T), dtype=torch.float64, device="cuda")
@@ -26,7 +26,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     flops = 2.0 * S * (N * (N + 1) / 2) * T
-    print("K_corr: %.1f us per call, %.2f TFLOP/s of the lower triangle" % (ms * 1e3, flops / (ms * 1e-3) / 1e12))
+    print("K_corr (S=%d, Nreg=%d, T=%d): %.1f us per call, %.2f TFLOP/s of the lower triangle" % (S, N, T, ms * 1e3, flops / (ms * 1e-3) / 1e12))
 
 
 if __name__ == "__main__":

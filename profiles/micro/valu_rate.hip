@@ -37,6 +37,13 @@ BODY(k_sdwa, "v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_
 BODY(k_pkadd, "v_pk_add_f32 %4, %4, %5\n v_pk_add_f32 %5, %5, %4")
 BODY(k_fmac64, "v_fmac_f64_e32 %4, 1.0, %5\n v_fmac_f64_e32 %5, 1.0, %4")
 BODY(k_fma64, "v_fma_f64 %4, %4, 1.0, %5\n v_fma_f64 %5, %5, 1.0, %4")
+BODY(k_cndmask_s, "v_cndmask_b32_e64 %0, %1, %0, s[20:21]\n v_cndmask_b32_e64 %2, %3, %2, s[20:21]")
+BODY(k_cndmask_c, "v_cndmask_b32_e64 %0, 0, 1, s[20:21]\n v_cndmask_b32_e64 %2, 0, 2, s[20:21]")
+BODY(k_addc, "v_addc_co_u32 %0, vcc, %1, %0, vcc\n v_addc_co_u32 %2, vcc, %3, %2, vcc")
+BODY(k_cmp, "v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %2, %3")
+BODY(k_cmp64, "v_cmp_lt_f64 vcc, %4, %5\n v_cmp_lt_f64 vcc, %5, %4")
+BODY(k_exp, "v_exp_f32 %0, %0\n v_exp_f32 %2, %2")
+BODY(k_cvt, "v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %2, %5")
 BODY(k_fmac32, "v_fmac_f32_e32 %0, 1.0, %1\n v_fmac_f32_e32 %2, 1.0, %3")
 
 int main() {
@@ -49,7 +56,7 @@ int main() {
         {"v_and_b32", k_and}, {"v_lshrrev_b32", k_lshr}, {"v_and_or_b32 (inline const)", k_andor}, {"v_and_b32 (literal)", k_andlit},
         {"v_add_u32", k_addu}, {"v_lshl_add_u32", k_lshladd}, {"v_bfe_u32", k_bfe}, {"v_mad_u32_u24", k_madu24}, {"v_perm_b32", k_perm},
         {"v_fma_f32", k_fma32}, {"v_add_f64", k_add64}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_lo_u32", k_mullo}, {"v_cndmask_b32", k_cndmask},
-        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}, {"v_fmac_f64_e32 (VOP2, x 1.0)", k_fmac64}, {"v_fma_f64 (VOP3)", k_fma64}, {"v_fmac_f32_e32", k_fmac32}};
+        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}, {"v_fmac_f64_e32 (VOP2, x 1.0)", k_fmac64}, {"v_fma_f64 (VOP3)", k_fma64}, {"v_fmac_f32_e32", k_fmac32}, {"v_cndmask_b32_e64 (SGPR-pair mask)", k_cndmask_s}, {"v_cndmask_b32_e64 (constants, SGPR mask)", k_cndmask_c}, {"v_addc_co_u32 (vcc in/out)", k_addc}, {"v_cmp_lt_f32 -> vcc", k_cmp}, {"v_cmp_lt_f64 -> vcc", k_cmp64}, {"v_exp_f32", k_exp}, {"v_cvt_f32_f64", k_cvt}};
     const int iters = 2000;
     uint64_t *h = (uint64_t *)malloc((size_t)cus * 4 * 8 * 8);
     for (auto &k : ks) {
