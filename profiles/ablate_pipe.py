@@ -34,9 +34,10 @@ def main():
         eng.sweeps(s, 1)
     torch.cuda.synchronize()
     cases = [("step-per-launch form, full", {"r_path": 3}), ("pipelined, full", {"r_path": 0}),
+             ("pipelined, one in-order workgroup per patient", {"r_path": 0, "r_dsplit": 1}),
              ("pipelined, no panel terms", {"r_path": 0, "FCD_ABL_PANEL": "2"}),
-             ("pipelined, no in-order terms", {"r_path": 0, "FCD_ABL_DIAG": "2"}),
-             ("pipelined, neither", {"r_path": 0, "FCD_ABL_PANEL": "2", "FCD_ABL_DIAG": "2"})]
+             ("pipelined, no panel terms, one in-order wg", {"r_path": 0, "r_dsplit": 1, "FCD_ABL_PANEL": "2"})]
+    # (round 3: the in-order scan carries no ablation switch any more -- one flag read inside its rows cost more than the rows)
     res = {name: [] for (name, _) in cases}
     for rnd in range(5):
         for (name, env) in cases:
@@ -47,6 +48,8 @@ def main():
                     os.environ[k] = v
                 else:
                     eng.ctx.set_knob(k, v)
+            if "r_dsplit" not in env:
+                eng.ctx.set_knob("r_dsplit", 0)
             eng.r_step(100)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
