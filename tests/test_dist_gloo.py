@@ -83,7 +83,7 @@ def run_single(total, n_sweeps, seed, mstep_every=1, lag=0, on_sweep=None):
     return eng
 
 
-def worker(rank, world, port, total, n_sweeps, seed, out_dir, mstep_every=1, lag=0):
+def worker(rank, world, port, total, n_sweeps, seed, out_dir, mstep_every=1, lag=0, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -91,7 +91,7 @@ def worker(rank, world, port, total, n_sweeps, seed, out_dir, mstep_every=1, lag
         (S_B, lM, Nreg, U, th) = problem()
         (chain0, n_local) = shard_chains(total, world, rank)
         eng = OracleEngine(S_B, lM, Nreg, U, n_local, chain0, seed, th["gamma"], th["pi"])
-        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag)
+        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=force)
         cnt = torch.from_numpy(eng.cnt_r.copy())
         dist.all_reduce(cnt)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=eng.f, r=eng.r, pi=eng.pi, gamma=eng.gamma,
@@ -151,3 +151,27 @@ def test_two_ranks_equal_one_process(tmp_path, mstep_every, lag):
         np.testing.assert_array_equal(p["gamma"], ref.gamma)
         np.testing.assert_array_equal(p["cnt_r"], ref.cnt_r)
     assert 0 < ref.pi < 1 and abs(ref.gamma.sum() - 1) < 1e-12
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (1, 1), (2, 1)])
+def test_group_of_one_rank_forced_collective(tmp_path, mstep_every, lag):
+    """
+    force_collective=True: the several-rank loop (counts -> all-reduce -> M-step between calls) in a process group of ONE
+    rank walks the chains of the plain loop (what bench.py --force-pg and tests/test_dist_nccl.py do with RCCL on one GPU).
+    Without a process group the flag changes nothing.
+    """
+    (total, n_sweeps, seed) = (7, 5, 41)
+    ref = run_single(total, n_sweeps, seed, mstep_every=mstep_every, lag=lag)
+    port = free_port()
+    mp.spawn(worker, args=(1, port, total, n_sweeps, seed, str(tmp_path), mstep_every, lag, True), nprocs=1, join=True)
+    p = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    np.testing.assert_array_equal(p["f"], ref.f)
+    np.testing.assert_array_equal(p["r"], ref.r)
+    assert float(p["pi"]) == ref.pi
+    np.testing.assert_array_equal(p["gamma"], ref.gamma)
+    np.testing.assert_array_equal(p["cnt_r"], ref.cnt_r)
+    (S_B, lM, Nreg, U, th) = problem()
+    eng = OracleEngine(S_B, lM, Nreg, U, total, 0, seed, th["gamma"], th["pi"])
+    run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=True)   # no group here
+    np.testing.assert_array_equal(eng.r, ref.r)
