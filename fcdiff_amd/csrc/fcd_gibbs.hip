@@ -759,6 +759,9 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
         }
     }
     if (!a.acc) return;
+    // Only the blocks that count take a ticket: the sums, the ticket and the M-step -- a chain of four trips to the memory
+    // side -- then run BESIDE the blocks that make the slot words instead of behind the last of them.
+    if (!r_role) return;
     // the r count: one atomic per BLOCK (same-address atomics serialise): wave sums -> LDS -> thread 0
     for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
     if (lane == 0) red[wave] = cr;
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) sh_last = (atomicAdd(&a.acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    if (threadIdx.x == 0) sh_last = (atomicAdd(&a.acc[4], 1ull) == (unsigned long long)nrb - 1ull) ? 1 : 0;
     __syncthreads();
     if (sh_last && threadIdx.x < 64) {
         // the five words are fetched (and reset) by five lanes at once: one memory round trip, not five in a row
