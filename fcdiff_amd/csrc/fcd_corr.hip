@@ -197,7 +197,9 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
                                                                  unsigned *__restrict__ ticket, double *__restrict__ tmp) {
     extern __shared__ __attribute__((aligned(16))) double csm[];
     const int RT = (Nreg + 15) >> 4, RP = RT * 16, NT = RT * (RT + 1) / 2;
-    double *dg = csm + 2 * RP * CLD, *sums = dg + RP, *sd = sums + RP;     // (csm: panels [2][RP][CLD] first)
+    // steps of SK = 32 samples (two halves of 16, staged one after the other): half as many barriers per MFMA as with 16
+    constexpr int SK = 32, SLD = 34;        // (rows padded to 34 doubles: the fragment reads stay conflict-free)
+    double *dg = csm + 2 * RP * SLD, *sums = dg + RP, *sd = sums + RP;     // (csm: panels [2][RP][SLD] first)
     __shared__ int sh_last;
     const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = l & 15, kq = l >> 4;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
     // workgroup -> (subject, slice ks of KS of the time axis)
     const int KS = PMAX;
     const int s = (int)blockIdx.x / KS, ks = (int)blockIdx.x % KS;
-    const int steps_all = (T + CK - 1) / CK, per = (steps_all + KS - 1) / KS;
+    const int steps_all = (T + SK - 1) / SK, per = (steps_all + KS - 1) / KS;
     const int st_lo = ks * per, st_hi = (st_lo + per < steps_all) ? st_lo + per : steps_all;
     const double *xp[NPI];
     double x0[NPI], rs[NPI];
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
     // before (anything done to them in fetch would wait for the loads in front of those MFMAs)
     double2 raw[NPI];
     int kf = 0;
-    auto fetch = [&](int st) {
-        kf = st * CK + 2 * pp;
+    auto fetch = [&](int st, int h) {              // half h (16 samples) of step st
+        kf = st * SK + h * 16 + 2 * pp;
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             if (even) {
@@ -253,53 +255,58 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
             }
         }
     };
-    auto put = [&](int buf) {
+    auto put = [&](int buf, int h) {
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             double2 v;
             v.x = (va[i] && kf < T) ? raw[i].x - x0[i] : 0.0;
             v.y = (va[i] && kf + 1 < T) ? raw[i].y - x0[i] : 0.0;
             rs[i] += v.x + v.y;
-            if (prow[i] < RP) *reinterpret_cast<double2 *>(&csm[buf * RP * CLD + prow[i] * CLD + 2 * pp]) = v;
+            if (prow[i] < RP) *reinterpret_cast<double2 *>(&csm[buf * RP * SLD + prow[i] * SLD + h * 16 + 2 * pp]) = v;
         }
     };
     double4_t acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // Two panels in LDS.  Step st: one barrier (panel st % 2 is complete, nobody reads the other one any more), the
-    // fragments of the first quarter, then the 24 MFMAs of the step -- behind every MFMA the fragments of the SAME tile for
-    // the next quarter (asked for a whole turn of the wave's six tiles before they are used), and behind the first
-    // quarter the step's share of the staging: the values of step st + 1 (asked for a step ago) are shifted, summed and
-    // put into the other panel, those of step st + 2 are asked for.  All of that issues while the matrix pipe works
-    // through the MFMAs of the SIMD's four waves; only the first fragments of a step wait for the LDS.
+    // Two panels in LDS.  Step st (32 samples): one barrier (panel st % 2 is complete, nobody reads the other one any
+    // more), the fragments of the first eighth, then the 48 MFMAs of the step -- behind every MFMA the fragments of the
+    // SAME tile for the next eighth (asked for a whole turn of the wave's six tiles before they are used) -- and, spread
+    // over the eighths, the staging of step st + 1: its first 16 samples are asked for behind eighth 0 and shifted, summed
+    // and parked in the other panel behind eighth 3, the second 16 behind eighths 4 and 7 (the same four registers
+    // twice).  All of that issues while the matrix pipe works through the MFMAs of the SIMD's four waves; only the first
+    // fragments of a step wait for the LDS.
     double fa[TPW], fb[TPW];
     auto frags = [&](int buf, int j, int g) {
         // (a slot beyond the last tile runs tile 0 again and is dropped at the end: no branch around an MFMA)
-        const double *P = csm + buf * RP * CLD + (i16 * CLD + kq);
-        fa[j] = P[tr[j] * (16 * CLD) + g * 4];
-        fb[j] = P[tc[j] * (16 * CLD) + g * 4];
+        const double *P = csm + buf * RP * SLD + (i16 * SLD + kq);
+        fa[j] = P[tr[j] * (16 * SLD) + g * 4];
+        fb[j] = P[tc[j] * (16 * SLD) + g * 4];
     };
     if (st_lo < st_hi) {
-        fetch(st_lo);
-        put(0);
-        if (st_lo + 1 < st_hi) fetch(st_lo + 1);
+        fetch(st_lo, 0);
+        put(0, 0);
+        fetch(st_lo, 1);
+        put(0, 1);
     }
     for (int st = st_lo; st < st_hi; ++st) {
         const int cur = (st - st_lo) & 1;
+        const bool more = st + 1 < st_hi;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < TPW; ++j) frags(cur, j, 0);
 #pragma unroll
-        for (int g = 0; g < CK / 4; ++g) {
+        for (int g = 0; g < SK / 4; ++g) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[j], fb[j], acc[j], 0, 0, 0);
-                if (g + 1 < CK / 4) frags(cur, j, g + 1);
+                if (g + 1 < SK / 4) frags(cur, j, g + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (g == 0 && st + 1 < st_hi) {
-                put(cur ^ 1);
-                if (st + 2 < st_hi) fetch(st + 2);
+            if (more) {
+                if (g == 0) fetch(st + 1, 0);
+                if (g == 3) put(cur ^ 1, 0);
+                if (g == 4) fetch(st + 1, 1);
+                if (g == 7) put(cur ^ 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -428,10 +435,10 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
     const int RT = (int)((Nreg + 15) / 16), RP = RT * 16, NT = RT * (RT + 1) / 2;
     if (NT <= 16 * TPW && ctx->knobs.corr_form != 1) {
         // slices of the time axis: about one workgroup per CU (S subjects alone would leave most CUs idle), no slice
-        // shorter than 4 steps
-        const int64_t steps_all = (T + CK - 1) / CK;
+        // shorter than 2 steps of 32 samples
+        const int64_t steps_all = (T + 31) / 32;                        // (the kernel's steps: 32 samples)
         int64_t KS = ctx->num_cu / S;
-        if (KS > steps_all / 4) KS = steps_all / 4;
+        if (KS > steps_all / 2) KS = steps_all / 2;
         if (KS < 1) KS = 1;
         if (KS > 16) KS = 16;
         const int64_t NWG = S * KS;
@@ -454,7 +461,7 @@ extern "C" int fcd_corr_edges(fcd_ctx *ctx, const double *ts, int64_t S, int64_t
         unsigned *ticket = (unsigned *)ctx->corr_tickets;
         double *part = (double *)ctx->ws;
         double *tmp = (double *)((char *)ctx->ws + part_bytes);
-        const size_t shmem = ((size_t)2 * RP * CLD + 3 * RP) * sizeof(double);
+        const size_t shmem = ((size_t)2 * RP * 34 + 3 * RP) * sizeof(double);      // (panels [2][RP][34]: the kernel's SLD)
         rc = fcd_lds_attr(ctx, FCD_KA_CORR, reinterpret_cast<const void *>(&corr_gram_subject_kernel<TPW>), shmem);
         if (rc) return rc;
         hipLaunchKernelGGL(corr_gram_subject_kernel<TPW>, dim3((unsigned)NWG), dim3(1024), shmem, s, ts, (int)Nreg, (int)T, S,
