@@ -849,7 +849,9 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
         const int rows_next = st + 1 < NBLK ? ((Nreg - (st + 1) * R_NB < R_NB) ? (Nreg - (st + 1) * R_NB) : R_NB) : 0;
         const bool more = row < rows_next;
         double2 nv[SU];
-        if (more) load_rows(n + R_NB, threadIdx.x, nv);
+        unsigned txp = threadIdx.x;                           // (opaque copy: the piece index is made here, not carried -- spilled -- across the step)
+        asm volatile("" : "+v"(txp));
+        if (more) load_rows(n + R_NB, (int)txp, nv);
         double th[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) th[u] = 0.0;
@@ -978,6 +980,11 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, i
         const int B0 = b * R_NB;
         const int nb = (Nreg - B0 < R_NB) ? (Nreg - B0) : R_NB;
         const bool hasA = b > 0;
+        // (the thread index behind an opaque copy: the staging / build addresses derived from it are made anew in every
+        //  block -- a dozen instructions -- instead of being lifted out of the loop, spilled for want of registers and
+        //  fetched back from scratch memory, one trip each, in the middle of every block's build)
+        unsigned tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
         // (block 0 has no tile A: its records are zero whatever the bytes say, so the f words of tile A are then read from
         // the block itself -- a valid address, no branch around the load)
         const int a_back = hasA ? 64 : 0;
@@ -1013,7 +1020,7 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, i
             constexpr int TILE_D2 = R_NB * R_NB * 3;
             double2 *dA = reinterpret_cast<double2 *>(sA), *dB = reinterpret_cast<double2 *>(sB);
             constexpr int SU = 2;
-            for (int it0 = threadIdx.x; it0 < 2 * TILE_D2; it0 += SU * blockDim.x) {
+            for (int it0 = (int)tx; it0 < 2 * TILE_D2; it0 += SU * blockDim.x) {
                 double2 v[SU];
 #pragma unroll
                 for (int j = 0; j < SU; ++j) {
@@ -1039,10 +1046,10 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, i
         __syncthreads();
         FCD_TRACE_VAL_AT(tr0, trec, 5, wall_clock64());
         {
-            const int q = threadIdx.x % 9, step = blockDim.x / 9;
+            const int q = tx % 9, step = blockDim.x / 9;
             const int k = q / 3, k2 = q - 3 * k;
-            const int r0 = threadIdx.x / 9;
-            const bool on = (int)threadIdx.x < step * 9;
+            const int r0 = tx / 9;
+            const bool on = (int)tx < step * 9;
             auto four = [&](const double *single_tile, int rec, double2 &lo, double2 &hi) {
                 const double2 a2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 2 * k);
                 const double2 b2 = *reinterpret_cast<const double2 *>(single_tile + rec * 12 + 6 + 2 * k2);
@@ -1186,9 +1193,12 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, i
                 const uint32_t ra = pb_off + (uint32_t)(stop * (R_NB / 2) * 288), rb = pb_off + (uint32_t)((R_NB + stop) * (R_NB / 2) * 288);
                 vstop = (e + (four(za, ra, 0) + four(za, ra, 4))) + (four(zb, rb, 0) + four(zb, rb, 4));
             }
-            if (__ballot(fabs(vstop) < a.tol) != 0ull)
-                vstop += pipe_exact_corr((uint32_t)((B0 + stop) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ulane,
-                                     a.sweep, a.seed, u & 1);
+            if (__ballot(fabs(vstop) < a.tol) != 0ull) {
+                uint32_t ul3 = ulane;           // (opaque copy: the chain number is made here, in the cold block, not carried through the scan)
+                asm volatile("" : "+v"(ul3));
+                vstop += pipe_exact_corr((uint32_t)((B0 + stop) * ((U + 1) >> 1) + (u >> 1)), a.chain0 + (uint32_t)w * 64u + ul3,
+                                         a.sweep, a.seed, u & 1);
+            }
             const uint32_t t = vstop > 0.0 ? 1u : 0u;
             fresh |= t << stop;
             const int sh = 8 * ((stop >> 1) & 3) + (stop & 1);
@@ -1209,7 +1219,9 @@ __device__ __forceinline__ void pipe_diag(const r_step_args &a, int u, int wg, i
         rpb = spread2(fresh);
         FCD_TRACE_AT(tr0, trec, 2);
         {
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.r_Sn + (wu * NBLK + b) * 64 + ulane);
+            uint32_t ul2 = ulane;                 // (opaque copy: the 64-bit lane offset is made here, not carried -- spilled -- across the block)
+            asm volatile("" : "+v"(ul2));
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.r_Sn + (wu * NBLK + b) * 64 + ul2);
             const unsigned long long val = (unsigned long long)rpb.x | ((unsigned long long)rpb.y << 32);
             __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
