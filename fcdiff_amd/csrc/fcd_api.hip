@@ -157,6 +157,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");
     ctx->knobs.r_nopad = (int)knob_env("FCD_R_NOPAD");
     ctx->knobs.r_dsplit = (int)knob_env("FCD_R_DSPLIT");
+    ctx->knobs.r_refill = (int)knob_env("FCD_R_REFILL");
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
     ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
@@ -235,6 +236,7 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_ub")) k.r_ub = (int)value;
     else if (!strcmp(name, "r_nopad")) k.r_nopad = (int)value;
     else if (!strcmp(name, "r_dsplit")) k.r_dsplit = (int)value;
+    else if (!strcmp(name, "r_refill")) k.r_refill = (int)value;
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;
     else if (!strcmp(name, "f_form")) k.f_form = (int)value;

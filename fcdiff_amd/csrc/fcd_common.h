@@ -21,6 +21,7 @@ struct fcd_knobs {
                        // per block step; 3: one launch per block step always
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups
+    int r_refill;      // 1: the packing launch writes the panel-value sentinels in every sweep (default: only in the first sweep of a fcd_gibbs_run call)
     int r_dsplit;      // 1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, where there are more than 8)
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
@@ -115,7 +116,7 @@ static inline int fcd_lds_attr(fcd_ctx *ctx, int slot, const void *fn, size_t sh
 // the plain entry points.  Symmetric edge ids only.
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready);
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready, size_t ru_off = 0);
 // The f half of the tally (pooled counts of f, marginal counters of the edges): it needs nothing of the r pass, so the r
 // pass's packing launch can carry it in extra workgroups of its own instead of the tally launch after the pass.
 struct fcd_tally_f {
@@ -125,11 +126,14 @@ struct fcd_tally_f {
     unsigned long long *acc;           // nullable: context-owned sums, [1..3] = number of f == 0, 1, 2
     uint32_t *cnt_f;                   // nullable
 };
-// tally_f != nullptr: asked to carry the f half; *tally_f_done says whether it did (the blocked path with a packing launch)
+// tally_f != nullptr: asked to carry the f half; *tally_f_done says whether it did (the blocked path with a packing launch).
+// sentinels_in_place: the two panel-value buffers at the head of the workspace still hold the sentinels a COMPLETED pipelined
+// pass of the same shape left there (every slot gets its sentinel back when its value is consumed): the packing launch
+// need not write them again.  ru_off (f pass): where in the workspace the slot words live.
 int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq,
-                        const fcd_tally_f *tally_f = nullptr, bool *tally_f_done = nullptr);
+                        const fcd_tally_f *tally_f = nullptr, bool *tally_f_done = nullptr, bool sentinels_in_place = false);
 // bracket ONE kernel launch with events when profiling is on (no-ops otherwise)
 void fcd_prof_begin(fcd_ctx *ctx, int slot, hipStream_t s);
 void fcd_prof_end(fcd_ctx *ctx, int slot, hipStream_t s);

@@ -1038,7 +1038,7 @@ size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {
 
 int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const double *lMf, const double *hyper,
                         uint8_t *f_state, const uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
-                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready) {
+                        uint64_t seed, int64_t sweep, hipStream_t stream, uint8_t *fsq, bool ru_ready, size_t ru_off) {
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
     if (rc) return rc;
@@ -1054,9 +1054,9 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
     if ((float)ctx->knobs.f_tol > margin) margin = (float)ctx->knobs.f_tol;   // test hook: huge = every draw through fcd_draw_f
     if (pl.form == F_PAIR || pl.form == F_PAIRX) {
         // pair / triple forms: per-lane slot words over patients (scratch in the ctx workspace), records in LDS
-        rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));
+        rc = fcd_ws_reserve(ctx, ru_off + fcd_f_pass_ws_bytes(Nreg, U, g.GW));
         if (rc) return rc;
-        uint32_t *r_U = (uint32_t *)ctx->ws;
+        uint32_t *r_U = (uint32_t *)((char *)ctx->ws + ru_off);
         if (!ru_ready) {     // (inside fcd_gibbs_run the previous sweep's tally has made them already)
             const int64_t items = (int64_t)g.GW * Nreg * pl.NW;
             hipLaunchKernelGGL(pack_ru_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, r_bits, (int)Nreg, (int)U, pl.NW,
@@ -1254,13 +1254,19 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
             fsq = (uint8_t *)ctx->fsq;
         }
     }
+    // The slot words of the f pass live BEHIND the r pass's workspace inside this loop (on their own they sit at its head):
+    // the r pass's two buffers of panel values then survive from one sweep to the next, and since a completed pipelined
+    // pass leaves every slot holding its sentinel again, only the first sweep of a call has to write them (13 MB at cfg3).
+    size_t ru_off = 0;
     if (pair_form) {
-        rc = fcd_ws_reserve(ctx, fcd_f_pass_ws_bytes(Nreg, U, g.GW));      // the tally writes the next pass's slot words there
+        ru_off = (fcd_r_pass_ws_bytes(Nreg, U, g.GW, ctx->knobs.r_path) + 511) / 512 * 512;
+        rc = fcd_ws_reserve(ctx, ru_off + fcd_f_pass_ws_bytes(Nreg, U, g.GW));      // the tally writes the next pass's slot words there
         if (rc) return rc;
     }
     bool ru_ready = false;
+    bool sentinels_in_place = false;
     for (int64_t i = 0; i < n_sweeps; ++i) {
-        rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready);
+        rc = fcd_gibbs_f_step_sq(ctx, S_B, lM, lMf, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, s, fsq, ru_ready, ru_off);
         if (rc) return rc;
         const bool last = i + 1 == n_sweeps;
         const bool do_m = mstep_every > 0 && (i + 1) % mstep_every == 0;
@@ -1273,10 +1279,11 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
         const bool want_f = tf.acc || tf.cnt_f;
         bool f_done = false;
         rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq,
-                                 want_f ? &tf : nullptr, &f_done);
+                                 want_f ? &tf : nullptr, &f_done, sentinels_in_place);
         if (rc) return rc;
+        sentinels_in_place = pair_form && ctx->r_form_last == 2;        // (a pipelined pass has just been queued)
         // the r pass's scratch is dead once its last launch is queued: the slot words of the next f pass go to its place
-        uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)ctx->ws : nullptr;
+        uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)((char *)ctx->ws + ru_off) : nullptr;
         int64_t *cts = (last ? counts : nullptr);
         if (do_m || do_a || cts || r_U_next) {
             rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,

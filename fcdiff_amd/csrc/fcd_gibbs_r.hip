@@ -167,7 +167,7 @@ __device__ __forceinline__ void pack_r_item(const uint64_t *__restrict__ r_bits,
                                             const r_pipe_init &pipe) {
     if (pipe.marks) {
         if (lane == 0) pipe.marks[((int64_t)w * U + u) * NBLK + b] = 0u;
-        if (b < 2) {                                     // (a single block never uses the second buffer)
+        if (b < 2 && pipe.P[b]) {                        // (a single block never uses the second buffer)
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(pipe.P[b]) + (((int64_t)w * U + u) * R_NB) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < R_NB; ++i) dst[i * 64] = R_SENT;
@@ -1440,7 +1440,7 @@ extern "C" int fcd_gibbs_r_step(fcd_ctx *ctx, const double *lM, const double *lM
 int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const double *hyper,
                         const uint8_t *f_state, uint64_t *r_bits, int64_t Nreg, int64_t U, int64_t G, int64_t chain0,
                         uint64_t seed, int64_t sweep, int edge_mode, hipStream_t stream, const uint8_t *fsq,
-                        const fcd_tally_f *tally_f, bool *tally_f_done) {
+                        const fcd_tally_f *tally_f, bool *tally_f_done, bool sentinels_in_place) {
     if (tally_f_done) *tally_f_done = false;
     fcd_geo g;
     int rc = fcd_geo_check(ctx, Nreg, U, G, chain0, g);
@@ -1537,8 +1537,10 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         if (rc) return rc;
         if (pipe) {
             pinit.marks = marks;
-            pinit.P[0] = Pb[0];
-            pinit.P[1] = Pb[1];
+            // (the sentinels: unless a completed pipelined pass of this shape left them in place -- fcd_gibbs_run knows)
+            const bool keep = sentinels_in_place && ctx->r_form_last == 2 && !ctx->knobs.r_refill;
+            pinit.P[0] = keep ? nullptr : Pb[0];
+            pinit.P[1] = keep ? nullptr : Pb[1];
         }
     }
     {

@@ -73,7 +73,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 /* Sizes every scratch buffer of the sweep at this shape (f / r pass workspace, square f copy): after it no
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
-/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
+/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_REFILL, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
  * FCD_CORR_FORM, FCD_R_POLL_LIMIT, FCD_R_WITHHOLD, read once by fcd_ctx_create; 0 = default everywhere):
  *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
  *                  kernel boundaries) wherever every workgroup is resident at once, else one launch per block step;
@@ -82,6 +82,8 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups
  *   "r_dsplit"  1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, on two CUs,
  *               where a group has more than 8 chain words and 2 U <= number of CUs)
+ *   "r_refill"  1: the pipelined r pass's packing launch writes the panel-value sentinels in every sweep (default: only in the
+ *               first sweep of a fcd_gibbs_run call -- a completed pass leaves every slot holding its sentinel again)
  *   "corr_form" 1: fcd_corr_edges in 64 x 64 blocks with a moments pass also where the one-workgroup-per-subject kernel
  *               (up to 208 regions) would run
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)

@@ -409,11 +409,13 @@ def test_gibbs_conditionals_against_reference_pins(env, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kn", [{"r_path": 3}, {"r_path": 3, "r_tol": 1e30}, {"r_path": 3, "r_ub": 1}, {"f_tol": 1e30}, {"f_form": 2},
                                 {"f_form": 2, "f_tol": 1e30}, {"f_form": 3}, {"r_path": 3, "r_nopad": 1},
-                                {}, {"r_tol": 1e30}, {"r_ub": 1}, {"r_nopad": 1}, {"r_dsplit": 1}, {"r_dsplit": 1, "r_tol": 1e30}],
+                                {}, {"r_tol": 1e30}, {"r_ub": 1}, {"r_nopad": 1}, {"r_dsplit": 1}, {"r_dsplit": 1, "r_tol": 1e30},
+                                {"r_refill": 1}],
                          ids=["step-per-launch", "exact-thresholds", "one-patient", "exact-f-draws", "any-U-f-kernel",
                               "any-U-f-kernel-exact", "scalar-mask-f-kernel", "no-pad",
                               "pipelined", "pipelined-exact", "pipelined-one-patient", "pipelined-no-pad",
-                              "pipelined-one-in-order-workgroup", "pipelined-one-in-order-workgroup-exact"])
+                              "pipelined-one-in-order-workgroup", "pipelined-one-in-order-workgroup-exact",
+                              "pipelined-sentinels-every-sweep"])
 @pytest.mark.parametrize("N,U,G,mode", [(40, 5, 128, "symmetric"), (37, 6, 1024, "reference")])
 def test_gibbs_r_pass_forms(env, knobs, kn, N, U, G, mode):
     """
@@ -846,6 +848,41 @@ def test_gibbs_cfg3_size_properties(env):
     assert mr > 1e-9 and mf > 1e-11
     lj = full.logjoint().cpu().numpy()
     nptest.assert_allclose(lj[:8], env.CO.gibbs_logjoint(f_g[:8].copy(), r_g[:8].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
+
+
+@pytest.mark.parametrize("N,U,G", [(40, 6, 1024), (97, 5, 320), (33, 9, 64)])
+def test_gibbs_run_keeps_the_sentinels_between_sweeps(env, knobs, N, U, G):
+    """
+    Inside ONE fcd_gibbs_run call the pipelined r pass's packing launch writes the panel-value sentinels in the first sweep
+    only (a completed pass leaves every slot holding its sentinel again; the f pass's slot words live behind the r pass's
+    workspace there): five sweeps in one call walk the oracle's chains, as do the same five sweeps with the sentinels
+    written every time (knob r_refill) and as five calls of one sweep; no device-side wait is given up.
+    """
+    (m, S_B, lM) = tables_for(env, N, 3, U, seed=N + G)
+    seed = 31 + N
+    lng, lnpi2 = np.log(m.gamma), np.log(m.pi2())
+    f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, seed, 0)
+    for s_ in range(5):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, lng, seed, s_, 0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, lnpi2, seed, s_, 1, 0)
+
+    def fresh():
+        e = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, seed=seed, ctx=env.ctx)
+        e.set_hyper(m.gamma, m.pi2())
+        e.init(0.3)
+        return e
+    for mode in ("one call", "refill", "five calls"):
+        knobs(r_refill=1 if mode == "refill" else 0)
+        e = fresh()
+        if mode == "five calls":
+            for s_ in range(5):
+                e.run(s_, 1, mstep_every=0)
+        else:
+            e.run(0, 5, mstep_every=0)
+        (f_g, r_g) = e.export_state()
+        assert env.ctx.stat("dev_err") == 0 and env.ctx.stat("r_form_last") == 2, mode
+        nptest.assert_array_equal(f_g, f_o, err_msg=mode)
+        nptest.assert_array_equal(r_g, r_o, err_msg=mode)
 
 
 def test_gibbs_cfg2_full_size_against_oracle(env):
