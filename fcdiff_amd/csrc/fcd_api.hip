@@ -162,8 +162,8 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
     ctx->knobs.f_form = (int)knob_env("FCD_F_FORM");
     ctx->knobs.corr_form = (int)knob_env("FCD_CORR_FORM");
-    ctx->knobs.r_poll_limit = (int)knob_env("FCD_R_POLL_LIMIT");
-    ctx->knobs.r_withhold = (int)knob_env("FCD_R_WITHHOLD");
+    ctx->knobs.r_poll_limit = 0;        // test hooks: through fcd_ctx_set_knob only, never from the environment
+    ctx->knobs.r_withhold = 0;
     ctx->r_form_last = 0;
     int rc = fcd_ws_reserve(ctx, 1u << 20);
     if (rc == FCD_OK) {
@@ -257,6 +257,10 @@ int fcd_ctx_check(fcd_ctx *ctx) {
 int fcd_ctx_clear_error(fcd_ctx *ctx) {
     if (!ctx) return FCD_ERR_ARG;
     if (ctx->dev_err) *ctx->dev_err = 0u;
+    // whatever an abandoned launch left in the context-owned accumulators / tickets (zero between launches by contract)
+    if (ctx->acc) FCD_HIP_TRY(hipMemset(ctx->acc, 0, 8 * sizeof(unsigned long long)));
+    if (ctx->corr_tickets && ctx->corr_tickets_n > 0)
+        FCD_HIP_TRY(hipMemset(ctx->corr_tickets, 0, (size_t)ctx->corr_tickets_n * sizeof(unsigned)));
     return FCD_OK;
 }
 

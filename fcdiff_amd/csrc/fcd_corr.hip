@@ -337,7 +337,11 @@ __global__ __launch_bounds__(1024) void corr_gram_subject_kernel(const double *_
                     __hip_atomic_store(mine + (int64_t)(w * TPW + j) * 256 + r * 64 + l, acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         if (tid < RP) __hip_atomic_store(mine + (int64_t)NT * 256 + tid, sums[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();                                   // (waits for every wave's stores to be acknowledged)
+        // every wave waits for the acknowledgement of ITS stores before the barrier: a barrier on this target waits for
+        // LDS traffic only (lgkmcnt), so without this the ticket could reach the memory side before another wave's
+        // partial tiles (the in-order role of the r pass does the same before its mark)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(&ticket[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == (unsigned)KS - 1u;

@@ -1280,7 +1280,12 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
         bool f_done = false;
         rc = fcd_gibbs_r_step_sq(ctx, lM, lMd, hyper, f_state, r_bits, Nreg, U, G, chain0, seed, sweep0 + i, edge_mode, s, fsq,
                                  want_f ? &tf : nullptr, &f_done, sentinels_in_place);
-        if (rc) return rc;
+        if (rc) {
+            // the packing launch may already have added this sweep's f counts into the context's accumulators and no tally
+            // will draw the ticket that zeroes them: leave them clean for the next call
+            if (tf.acc) (void)hipMemsetAsync(ctx->acc, 0, 8 * sizeof(unsigned long long), s);
+            return rc;
+        }
         sentinels_in_place = pair_form && ctx->r_form_last == 2;        // (a pipelined pass has just been queued)
         // the r pass's scratch is dead once its last launch is queued: the slot words of the next f pass go to its place
         uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)((char *)ctx->ws + ru_off) : nullptr;
@@ -1288,7 +1293,10 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
         if (do_m || do_a || cts || r_U_next) {
             rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
                               do_m ? hyper : nullptr, r_U_next, pl.NW, s, f_done);
-            if (rc) return rc;
+            if (rc) {
+                if (tf.acc) (void)hipMemsetAsync(ctx->acc, 0, 8 * sizeof(unsigned long long), s);
+                return rc;
+            }
         }
         ru_ready = r_U_next != nullptr;
     }

@@ -74,7 +74,8 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
 /* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_REFILL, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
- * FCD_CORR_FORM, FCD_R_POLL_LIMIT, FCD_R_WITHHOLD, read once by fcd_ctx_create; 0 = default everywhere):
+ * FCD_CORR_FORM, read once by fcd_ctx_create; 0 = default everywhere; the two test hooks at the end of the list are NOT read
+ * from the environment -- a stray variable must not be able to make a fit give up):
  *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
  *                  kernel boundaries) wherever every workgroup is resident at once, else one launch per block step;
  *               3: one launch per block step always
@@ -102,7 +103,8 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out);
  * of a panel value is bounded, ~1 s), else FCD_OK.  The word is written by the device: call this AFTER the stream has been
  * synchronised (or after any device-to-host read that follows the sweeps on that stream) -- the sampler entry points
  * themselves only see a give-up of an EARLIER call.  Once set, the chain state is unusable; fcd_ctx_clear_error resets
- * the word after the caller has re-initialised its chains. */
+ * the word after the caller has re-initialised its chains, and puts the context-owned accumulators and tickets (pooled
+ * counts of the tally, K_corr's per-subject tickets) back to zero (it synchronises: an error-recovery call). */
 int fcd_ctx_check(fcd_ctx *ctx);
 int fcd_ctx_clear_error(fcd_ctx *ctx);
 

@@ -311,6 +311,55 @@ def test_vb_iteration_cfg2_size_against_c_oracle(env):
     nptest.assert_allclose(fit._energy_terms(), t, rtol=1e-10)
 
 
+def test_update_lps_cost_and_data_contract_cfg3_shape(env):
+    """
+    VERDICT r3 item 1: _update_lps() is called once per variational iteration (fcdiff/fit.py:75-82) and must cost a
+    kernel, not a host digest of b / bt (round 3: CRC-32 of 16 MB per call, 8.6 ms per iteration at cfg3).  Ten calls
+    at cfg3's shape, each under 1 ms; and the data contract of `data_check` through the fit itself.
+    """
+    import time
+    (N, H, U) = (200, 50, 50)
+    m = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=3)
+    fit = new_fit(env)
+    fit.b, fit.bt, fit.model = b, bt, m
+    fit._init_lps(N, H, U)
+    fit._update_lps()
+    env.torch.cuda.synchronize()
+    times = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        fit._update_lps()
+        env.torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    assert max(times) < 1e-3, times
+    lM0 = fit._lM
+    # whole-column edit in place: seen by the default sample
+    bt[:, 7] = np.clip(bt[:, 7] * 0.5, -1, 1)
+    fit._update_lps()
+    lM1 = fit._lM
+    assert not np.array_equal(lM1[:, 7], lM0[:, 7])
+    nptest.assert_array_equal(lM1[:, 8], lM0[:, 8])
+    # single-element edit: documented to need invalidate_data() under the default, seen by data_check='full'
+    bt[4321, 9] = 0.123456
+    fit.invalidate_data()
+    fit._update_lps()
+    lM2 = fit._lM
+    assert not np.array_equal(lM2[4321, 9], lM1[4321, 9])
+    fit.data_check = "full"
+    fit._update_lps()
+    bt[4322, 9] = -0.123456
+    fit._update_lps()
+    assert not np.array_equal(fit._lM[4322, 9], lM2[4322, 9])
+    # rebinding to another array is always seen
+    fit.data_check = "none"
+    fit.bt = bt.copy()
+    fit.bt[0, 0] = 0.5
+    fit._update_lps()
+    S_B, lM = env.CO.lik_tables(b, fit.bt, m.theta())
+    nptest.assert_allclose(fit._lM, lM, **TAB)
+
+
 # ------------------------------------------------------------------------------------------------
 # Gibbs sampler
 # ------------------------------------------------------------------------------------------------
@@ -534,6 +583,16 @@ def test_gibbs_pipelined_give_up_is_reported(env):
     env.CO.gibbs_r_step(f_o, r_o, lM, np.log(m.pi2()), 5, 0, env.lib.EDGE_MODES["symmetric"], 0)
     f_g, r_g = eng.export_state()
     nptest.assert_array_equal(r_g, r_o)
+    # ... and its pooled accumulators are clean (fcd_ctx_clear_error puts them back to zero; an abandoned
+    # call must not leak counts into the next M-step): one more sweep with the M-step inside the tally launch
+    c = eng.run(1, 1, mstep_every=1, want_counts=True).cpu().numpy()
+    f_g, r_g = eng.export_state()
+    assert c[0] == r_g.sum() and c[4] == G and [c[1 + k] for k in range(3)] == [(f_g == k).sum() for k in range(3)]
+    from fcdiff_amd.gibbs import mstep_from_counts
+    (gamma, pi) = eng.hyper_values()
+    (pi_h, gamma_h) = mstep_from_counts(c, N, U)
+    nptest.assert_allclose(pi, pi_h, rtol=1e-14)
+    nptest.assert_allclose(gamma, gamma_h, rtol=1e-14)
     ctx.close()
 
 
