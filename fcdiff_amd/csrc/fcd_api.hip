@@ -141,6 +141,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->fsq = nullptr;
     ctx->fsq_bytes = 0;
     ctx->acc = nullptr;
+    ctx->dbg = nullptr;
     ctx->corr_tickets = nullptr;
     ctx->corr_tickets_n = 0;
     ctx->prof_on = 0;
@@ -189,6 +190,9 @@ int fcd_ctx_create(fcd_ctx **out) {
         if (e == hipSuccess) e = hipMalloc(&ctx->acc, 8 * sizeof(unsigned long long));
         ctx->n_alloc += 1;
         if (e == hipSuccess) e = hipMemset(ctx->acc, 0, 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&ctx->dbg, 8 * sizeof(unsigned long long));
+        ctx->n_alloc += 1;
+        if (e == hipSuccess) e = hipMemset(ctx->dbg, 0, 8 * sizeof(unsigned long long));
         if (e != hipSuccess) {
             fcd_ctx_destroy(ctx);
             return (int)e;
@@ -206,6 +210,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (ctx->dev_err) (void)hipHostFree((void *)ctx->dev_err);
     if (ctx->fsq) (void)hipFree(ctx->fsq);
     if (ctx->acc) (void)hipFree(ctx->acc);
+    if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->corr_tickets) (void)hipFree(ctx->corr_tickets);
     for (int i = 0; i < FCD_PROF_SLOTS; ++i) {
         for (int j = 0; j < 2 * ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
@@ -271,6 +276,12 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out) {
     else if (!strcmp(name, "fsq_bytes")) *out = (int64_t)ctx->fsq_bytes;
     else if (!strcmp(name, "r_form_last")) *out = ctx->r_form_last;
     else if (!strcmp(name, "dev_err")) *out = ctx->dev_err ? (int64_t)*ctx->dev_err : 0;
+    else if (!strcmp(name, "f_repeats") || !strcmp(name, "r_exact_rows")) {
+        // event counters kept on the device (a synchronising read: diagnostics only)
+        unsigned long long v[8];
+        FCD_HIP_TRY(hipMemcpy(v, ctx->dbg, sizeof(v), hipMemcpyDeviceToHost));
+        *out = (int64_t)v[name[0] == 'f' ? 0 : 1];
+    }
     else return FCD_ERR_ARG;
     return FCD_OK;
 }

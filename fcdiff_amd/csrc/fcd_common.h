@@ -50,6 +50,8 @@ struct fcd_ctx {
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
+    void *dbg;         // 8 x uint64 event counters (fcd_ctx_stat): [0] waves of the f pass that repeated an edge's sums in fp64,
+                       // [1] rows of the r pass's in-order role decided on the exact path; never reset by the library
     void *corr_tickets;            // K_corr: one ticket per subject, zero between launches (the last taker resets it)
     size_t corr_tickets_n;
     void *fsq;         // square copy of the f state [w][n][m][lane] kept by fcd_gibbs_sweeps between its f and r pass
@@ -220,19 +222,44 @@ __device__ static inline int fcd_draw_f(double a0, double a1, double a2, double 
     return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
 }
 
-// The same draw from three hardware fp32 exponentials (~20 instructions instead of ~150).  *amb is set when x * sum
-// comes within `margin` (relative to the sum) of a boundary of the inverse CDF: the caller then repeats the draw with
-// fcd_draw_f, so the outcome is always fcd_draw_f's.  The fp32 weights are good to ~1e-5 relative (argument rounding
-// times |argument| <= 87, then 1 ulp): FCD_DRAW_F_MARGIN leaves an order of magnitude.
-#define FCD_DRAW_F_MARGIN 1e-4f
-__device__ static inline int fcd_draw_f_fast(double a0, double a1, double a2, double x, float margin, bool *amb) {
-    const double mx = fmax(a0, fmax(a1, a2));
-    const float e0 = __expf((float)(a0 - mx)), e1 = __expf((float)(a1 - mx)), e2 = __expf((float)(a2 - mx));
+// The same draw from three hardware fp32 exponentials (~20 instructions instead of ~150), for log-odds b1, b2 against type 0
+// that are themselves only known to within +-delta (fp32 accumulation of the f pass; 0 for fp64 sums).  *amb is set when the
+// outcome could be another one in exact arithmetic: the caller then repeats the draw with fcd_draw_f on fp64 sums, so the
+// outcome is always fcd_draw_f's.  After the shift by the largest exponent ONE weight is exactly 1; the other two carry a
+// relative uncertainty eta = e^(2 delta) - 1 (both b's off in opposite directions) + 2e-5 (fp32 exp: argument rounding
+// times |argument| <= 87, then 1 ulp), so x * sum and either boundary move by at most eta * (sum - 1) each -- an
+// uncertainty RELATIVE TO THE WEIGHT OFF THE MODE, not to the sum: a conditional that is all but one-hot (the usual case)
+// never repeats on account of it.  `floor_rel` * sum covers the fp32 roundings of x, the sum and the product (default
+// FCD_DRAW_F_MARGIN; the test hook f_tol raises it: 1e30 sends every draw down the exact path).  NaN-safe: a NaN or
+// infinite sum or bound is ambiguous.
+#define FCD_DRAW_F_MARGIN 1e-6f
+__host__ __device__ static inline float fcd_draw_f_eta(float delta) { return expm1f(2.0f * delta) * 1.001f + 2e-5f; }
+__device__ static inline int fcd_draw_f_fast(double b1, double b2, double x, float eta, float floor_rel, bool *amb) {
+    const double mx = fmax(0.0, fmax(b1, b2));
+    const float e0 = __expf((float)(0.0 - mx)), e1 = __expf((float)(b1 - mx)), e2 = __expf((float)(b2 - mx));
     const float s = (e0 + e1) + e2;
-    const float t = (float)x * s, m = margin * s;
-    *amb = fabsf(t - e0) < m || fabsf(t - (e0 + e1)) < m;
+    const float t = (float)x * s;
+    const float m = 2.0f * eta * (s - 1.0f) + floor_rel * s;
+    *amb = !(fabsf(t - e0) >= m && fabsf(t - (e0 + e1)) >= m);
     return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
 }
+// The draw entirely in fp32 (the pair forms of the f pass: their sums are fp32 already): bf1, bf2 = log-odds against type 0
+// known to within +-delta, eta = fcd_draw_f_eta(delta), xf = the uniform rounded to fp32 (covered by floor_rel).  Same rule,
+// same outcomes.
+__device__ static inline int fcd_draw_f_fast32(float bf1, float bf2, float xf, float eta, float floor_rel, bool *amb) {
+    const float mx = fmaxf(0.f, fmaxf(bf1, bf2));
+    const float e0 = __expf(0.f - mx), e1 = __expf(bf1 - mx), e2 = __expf(bf2 - mx);
+    const float s = (e0 + e1) + e2;
+    const float t = xf * s;
+    const float m = 2.0f * eta * (s - 1.0f) + floor_rel * s;
+    *amb = !(fabsf(t - e0) >= m && fabsf(t - (e0 + e1)) >= m);
+    return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
+}
+// absolute error bound of an fp32 sum of n terms, each first rounded to fp32, given B >= sum of |terms|: the n conversions
+// cost at most 2^-24 B together, each of the n - 1 additions at most 2^-24 times a partial sum of magnitude <= B
+__host__ __device__ static inline float fcd_f32_sum_err(int n_terms, float B) { return (float)(n_terms + 1) * 5.97e-8f * 1.01f * B; }
+// ... and of  (float)c + that sum  for an offset |c| <= cm: the offset's conversion and one more addition
+__host__ __device__ static inline float fcd_f32_offset_err(float cm, float B) { return 2.0f * 5.97e-8f * 1.01f * (cm + B); }
 
 // r = 1 with probability sigmoid(s1 - s0):  x < 1/(1+exp(s0-s1))  <=>  logit(x) < s1 - s0.
 // The threshold depends on the random number only, so it is computed off the region-to-region chain.

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
         }
         const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
         bool amb;
-        int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
+        int k = fcd_draw_f_fast(b1, b2, x, 2e-5f, margin, &amb);
         if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);      // too close to a boundary somewhere in the wave
         f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)k;
     }
@@ -259,17 +259,52 @@ __global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict
 }
 
 constexpr int FP_EC = 8;     // edges per tile
+typedef float fcd_f2v __attribute__((ext_vector_type(2)));           // one ds_read_b64, one v_pk_add_f32
+typedef __attribute__((address_space(3))) const fcd_f2v lds_cf2v;
+
+// The exact path of the pair forms: the two log-odds sums of edge c for this lane's chain in fp64, straight from the
+// table (48 contiguous bytes per patient: L2), in the order of the fp64 pair records of rounds 2-3 (record = row u + row
+// u+1, records summed in pair order).  zs: the slot word of a group of 8 pairs, np pairs of it used.
+__device__ __forceinline__ void fcd_f_exact_group(const double *__restrict__ row, int U, int u0, int np, uint32_t zs,
+                                                  bool &first, double &b1, double &b2) {
+#pragma unroll 1
+    for (int p = 0; p < np; ++p) {
+        const uint32_t f = (zs >> (4 * p)) & 15u;
+        const int l0 = (f & 4u) ? 1 : ((f & 1u) ? 2 : 0), l1 = (f & 8u) ? 1 : ((f & 2u) ? 2 : 0);   // 0 typical, 1 both, 2 discordant
+        const int u = u0 + 2 * p;
+        const double2 va = *reinterpret_cast<const double2 *>(row + ((int64_t)u * 3 + l0) * 2);
+        double r1 = va.x, r2 = va.y;
+        if (u + 1 < U) {
+            const double2 vb = *reinterpret_cast<const double2 *>(row + ((int64_t)(u + 1) * 3 + l1) * 2);
+            r1 += vb.x;
+            r2 += vb.y;
+        }
+        if (first) {
+            b1 = r1;
+            b2 = r2;
+            first = false;
+        } else {
+            b1 += r1;
+            b2 += r2;
+        }
+    }
+}
+
 template <int NW16>
 __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                             const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
-                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin, uint8_t *__restrict__ fsq) {
-    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [FP_EC][NPAIR][16][2] | singles [FP_EC][U][3][2]
-    double *tile = ptile;
+                                                            int GW, uint32_t chain0, uint64_t seed, uint32_t sweep, float margin, uint8_t *__restrict__ fsq,
+                                                            unsigned long long *__restrict__ dbg) {
+    // pair records [NPAIR][FP_EC][16] float2 | per-edge constants [FP_EC] float4 | singles [FP_EC][U][3][2] double
+    extern __shared__ __attribute__((aligned(256))) double ptile[];
     const int NPAIR = (U + 1) >> 1;
     const int64_t c0 = (int64_t)blockIdx.x * FP_EC;
     const int ne = (int)((C - c0 < FP_EC) ? (C - c0) : FP_EC);
-    double2 *single = reinterpret_cast<double2 *>(tile) + (size_t)FP_EC * NPAIR * 16;
+    float4 *edge_k = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ptile) + (size_t)FP_EC * NPAIR * 128);
+    double2 *single = reinterpret_cast<double2 *>(reinterpret_cast<char *>(edge_k) + FP_EC * 16);
+    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
+    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
@@ -302,8 +337,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     }
     __syncthreads();
     {
-        // pair records from the single rows in LDS: a thread keeps its slot (blockDim is a multiple of 16)
-        double2 *dst = reinterpret_cast<double2 *>(tile);
+        // pair records from the single rows in LDS: a thread keeps its slot (blockDim is a multiple of 16).  The records are
+        // fp32 (one rounding of the fp64 sum of the two rows): half the LDS, and a term is one 8-byte read and ONE packed add.
+        fcd_f2v *dst = reinterpret_cast<fcd_f2v *>(ptile);
         const int slot = threadIdx.x & 15;
         const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
         const bool valid = !((x0 & a0) | (x1 & a1));
@@ -329,20 +365,40 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                     v.y += v1.y;
                 }
             }
-            dst[(pr * FP_EC + e) * 16 + slot] = v;       // [pair][edge][slot]: see the reads below
+            fcd_f2v o;
+            o.x = (float)v.x;
+            o.y = (float)v.y;
+            dst[(pr * FP_EC + e) * 16 + slot] = o;       // [pair][edge][slot]: see the reads below
+        }
+        // B_e >= sum over the pairs of max |record entry|: the sum over the patients of the largest |value| of the row
+        // (wave e does edge e, lane = patient; U <= 64) -- what bounds the error of the fp32 sums below
+        for (int ee = (int)(threadIdx.x >> 6); ee < ne; ee += (int)(blockDim.x >> 6)) {      // (a workgroup may have fewer waves than edges)
+            float a = 0.f;
+            if (lane < U) {
+                const double2 *su = single + (ee * U + lane) * 3;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) a = fmaxf(a, fmaxf((float)fabs(su[l].x), (float)fabs(su[l].y)));
+                a *= 1.0000002f;                              // (the conversions above round to nearest)
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) {
+                // the edge's constants as the draw wants them: the two log-odds offsets in fp32 and the relative uncertainty
+                // of the weights that the error bound of the whole fp32 sum (NPAIR records, then the offset) amounts to
+                const int64_t c = c0 + ee;
+                const double c1 = lg1 + (S_B[c * 3 + 1] - S_B[c * 3 + 0]), c2 = lg2 + (S_B[c * 3 + 2] - S_B[c * 3 + 0]);
+                const float cm = fmaxf((float)fabs(c1), (float)fabs(c2)) * 1.0000002f;
+                edge_k[ee] = make_float4((float)c1, (float)c2, fcd_draw_f_eta(fcd_f32_sum_err(NPAIR, a) + fcd_f32_offset_err(cm, a)), 0.f);
+            }
         }
     }
     __syncthreads();
     if (w >= GW) return;
     if (FCD_ABL(0, 3)) return;           // ablation: staging only
     const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
-    const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
-    const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
     const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
-    typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
-    typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
     // The records lie [pair][edge][slot] from LDS address 0 (the kernel declares no static LDS: the host asks the runtime
     // before the first launch), so with the loops over edges, groups and pairs unrolled the record's address is an
     // IMMEDIATE of the read and a term's address costs a shift and a mask -- whatever the number of patients.
@@ -365,46 +421,65 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                     rmn[j] = ru[(uint32_t)((nm * NW16 + j) * 64) + ul];
                 }
             }
-            double b1 = 0.0, b2 = 0.0;
+            fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds, none waits for the one before
 #pragma unroll
             for (int g = 0; g < NW16; ++g) {
                 if (g < NG) {
                     const uint32_t zs = Zc[g];
                     if (NPAIR - 8 * g >= 8) {
+                        // eight reads asked for together, then the eight packed adds
+                        fcd_f2v v[8];
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
-                            // slot -> 16-byte records: byte offset = slot << 4
-                            const uint32_t ad = (p == 0) ? (zs << 4) & 0xF0u : (zs >> (4 * p - 4)) & 0xF0u;
-                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(((g * 8 + p) * FP_EC + e) * 256));
-                            if (g == 0 && p == 0) {          // (the sums start from the first term, not from 0 + the first term)
-                                b1 = v.x;
-                                b2 = v.y;
+                            // slot -> 8-byte records: byte offset = slot << 3
+                            const uint32_t ad = (p == 0) ? (zs << 3) & 0x78u : (zs >> (4 * p - 3)) & 0x78u;
+                            v[p] = *(lds_cf2v *)(uintptr_t)(ad + (uint32_t)(((g * 8 + p) * FP_EC + e) * 128));
+                        }
+#pragma unroll
+                        for (int p = 0; p < 8; p += 2) {
+                            if (g == 0 && p == 0) {          // (the sums start from the first terms, not from 0 + the first terms)
+                                acc = v[0];
+                                acc1 = v[1];
                             } else {
-                                b1 += v.x;
-                                b2 += v.y;
+                                acc += v[p];
+                                acc1 += v[p + 1];
                             }
                         }
+                        __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);     // the addresses (VALU)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the reads (DS read)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // the adds
                     } else {
                         for (int p = 0; p < NPAIR - 8 * g; ++p) {
-                            const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
-                            const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + (uint32_t)(((g * 8 + p) * FP_EC + e) * 256));
-                            b1 += v.x;
-                            b2 += v.y;
+                            const uint32_t off = ((zs >> (4 * p)) & 15u) << 3;
+                            const fcd_f2v v = *(lds_cf2v *)(uintptr_t)(off + (uint32_t)(((g * 8 + p) * FP_EC + e) * 128));
+                            acc += v;
                         }
                     }
                 }
             }
-            b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
-            b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+            acc += acc1;
+            const float4 ek = edge_k[e];
             if (FCD_ABL(0, 2)) {             // ablation: no RNG / exp
-                f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(b1 > b2 ? 1 : 2);
+                f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(acc.x > acc.y ? 1 : 2);
                 continue;
             }
             if ((e & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);   // c0 is a multiple of 8
-            const double x = fcd_u32(fcd_word(rnd, e & 3));
+            const uint32_t xw = fcd_word(rnd, e & 3);
             bool amb;
-            int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
-            if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
+            int k = fcd_draw_f_fast32(ek.x + acc.x, ek.y + acc.y, (float)xw * 2.3283064e-10f, ek.z, margin, &amb);
+            if (__ballot(amb) != 0ull) {
+                // somewhere in the wave the fp32 sums cannot decide the draw: the edge again, in fp64, for the whole wave
+                bool first = true;
+                double b1 = 0.0, b2 = 0.0;
+                const double *row = lMf + c * U * 6;
+#pragma unroll
+                for (int g = 0; g < NW16; ++g)
+                    if (g < NG) fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), Zc[g], first, b1, b2);
+                b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
+                b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+                k = fcd_draw_f(0.0, b1, b2, fcd_u32(xw));
+                if (lane == 0) atomicAdd(dbg, 1ull);
+            }
             (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
             if (fsq) {
                 // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
@@ -440,8 +515,10 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                                                                 const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
                                                                 const uint32_t *__restrict__ r_U, int Nreg, int U, int64_t C,
                                                                 int GW, uint32_t chain0, uint64_t seed, uint32_t sweep,
-                                                                float margin, uint8_t *__restrict__ fsq) {
-    extern __shared__ __attribute__((aligned(256))) double ptile[];   // pairs [EC][NPAIR][16][2] | staging scratch [waves][2][24][2]
+                                                                float margin, uint8_t *__restrict__ fsq,
+                                                                unsigned long long *__restrict__ dbg) {
+    // pairs [EC][NPAIR][16] float2 | per-edge constants [8] float4 | staging scratch [waves][2][24] double2
+    extern __shared__ __attribute__((aligned(256))) double ptile[];
     const int NPAIR = (U + 1) >> 1, NW16 = (U + 15) >> 4;
     const int64_t c0 = (int64_t)blockIdx.x * EC;
     const int ne = (int)((C - c0 < EC) ? (C - c0) : EC);
@@ -453,16 +530,20 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
     const uint32_t ul = (uint32_t)lane;
     // slot words of the first group of the first edge: requested before the build so that their latency hides behind it
     uint32_t rn_c = ru[(uint32_t)((wn * NW16) * 64) + ul], rm_c = ru[(uint32_t)((wm * NW16) * 64) + ul];
+    float4 *edge_k = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ptile) + (size_t)EC * NPAIR * 128);   // [8]
+    if (threadIdx.x < EC) edge_k[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     {
         // Pair records from the tile's rows of lMf, every byte of the table loaded ONCE: a wave takes a group of four
         // pairs of one edge (8 patients = 384 contiguous bytes, fewer at the end of a row; missing patients read as
         // zero records), lanes 0..23 load one 16-byte value each into the wave's own LDS scratch, then every lane makes
-        // the record entry of its (pair, slot) from two scratch values.  Two groups per turn, their loads in flight together.
+        // the record entry of its (pair, slot) from two scratch values -- rounded ONCE to fp32.  Two groups per turn, their
+        // loads in flight together.
         // (The 16 lanes of a pair loading their two operands straight from memory cost 2.9x the table's bytes in L2
         // misses at cfg5: the same line requested by several instructions in flight.)
         const int wv = (int)(threadIdx.x >> 6);
-        double2 *scratch = reinterpret_cast<double2 *>(ptile) + (size_t)EC * NPAIR * 16 + wv * (2 * 24);
-        double2 *dst = reinterpret_cast<double2 *>(ptile);
+        double2 *scratch = reinterpret_cast<double2 *>(reinterpret_cast<char *>(edge_k) + 128) + wv * (2 * 24);
+        fcd_f2v *dst = reinterpret_cast<fcd_f2v *>(ptile);
         const int slot = lane & 15, pl = lane >> 4;
         const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
         const bool valid = !((x0 & a0) | (x1 & a1));
@@ -501,8 +582,23 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                 const int g = g0 + t * nwv;
                 const int pr = eq[t][1] * 4 + pl;
                 const double2 va = scratch[t * 24 + pl * 6 + l0], vb = scratch[t * 24 + pl * 6 + 3 + l1];
-                const double2 r = valid ? make_double2(va.x + vb.x, va.y + vb.y) : make_double2(0.0, 0.0);
+                fcd_f2v r = {0.f, 0.f};
+                if (valid) {
+                    r.x = (float)(va.x + vb.x);
+                    r.y = (float)(va.y + vb.y);
+                }
                 if (g < groups && pr < NPAIR) dst[(eq[t][0] * NPAIR + pr) * 16 + slot] = r;
+                // the edge's bound B_e (sum over its patients of the largest |value| of the patient's row): lanes 0..7 take one
+                // patient of the group each, the edge's sum gathers in LDS (any order: it only sets how cautious the draw is)
+                if (g < groups && lane < 8) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const double2 q = scratch[t * 24 + lane * 3 + l];
+                        a = fmaxf(a, fmaxf((float)fabs(q.x), (float)fabs(q.y)));
+                    }
+                    atomicAdd(&edge_k[eq[t][0]].w, a * 1.0000002f);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                                        // the scratch is free for the next turn
@@ -510,15 +606,23 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
         }
     }
     __syncthreads();
-    if (w >= GW) return;
-    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
     const double lg1 = hyper[FCD_H_LNGAMMA + 1] - hyper[FCD_H_LNGAMMA + 0];
     const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
+    if ((int)threadIdx.x < ne) {
+        // the edge's constants as the draw wants them: the two log-odds offsets in fp32 and the error bound of the whole
+        // fp32 sum (NPAIR records + the offset + the initial zero)
+        const int64_t c = c0 + threadIdx.x;
+        const double c1 = lg1 + (S_B[c * 3 + 1] - S_B[c * 3 + 0]), c2 = lg2 + (S_B[c * 3 + 2] - S_B[c * 3 + 0]);
+        const float cm = fmaxf((float)fabs(c1), (float)fabs(c2)) * 1.0000002f;
+        const float a = edge_k[threadIdx.x].w;
+        edge_k[threadIdx.x] = make_float4((float)c1, (float)c2, fcd_draw_f_eta(fcd_f32_sum_err(NPAIR + 1, a) + fcd_f32_offset_err(cm, a)), 0.f);
+    }
+    __syncthreads();
+    if (w >= GW) return;
+    const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
     const int NG = (NPAIR + 7) >> 3;     // groups of 8 pairs = 16 patients = one slot word
-    typedef double fcd_d2v __attribute__((ext_vector_type(2)));           // native 16-byte vector: one ds_read_b128
-    typedef __attribute__((address_space(3))) const fcd_d2v lds_cd2v;
     const uint32_t tile_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ptile;   // 256-aligned
 
     for (int e = 0; e < ne; ++e) {
@@ -529,43 +633,59 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
             nm = 0;
             nn = (nn + 1 < Nreg) ? nn + 1 : nn;
         }
-        const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 256));
-        double b1 = 0.0, b2 = 0.0;
+        const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 128));
+        fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds
         for (int g = 0; g < NG; ++g) {
             // slot words of the next group (of the next edge after the last group): always loaded, from a valid place
             const bool last = g + 1 == NG;
             const int pn = last ? nn : wn, pm = last ? nm : wm, pg = last ? 0 : g + 1;
             const uint32_t rn_n = ru[(uint32_t)((pn * NW16 + pg) * 64) + ul], rm_n = ru[(uint32_t)((pm * NW16 + pg) * 64) + ul];
             const uint32_t zs = (rn_c ^ rm_c) | ((rn_c & rm_c) << 2);
-            const uint32_t gb = tb + (uint32_t)(g * (8 * 256));
+            const uint32_t gb = tb + (uint32_t)(g * (8 * 128));
             if (NPAIR - 8 * g >= 8) {
+                fcd_f2v v[8];
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
-                    const uint32_t sh = (p == 0) ? (zs << 4) : (zs >> (4 * p - 4));
+                    const uint32_t sh = (p == 0) ? (zs << 3) : (zs >> (4 * p - 3));
                     uint32_t ad;
-                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0xF0u), "v"(gb));
-                    const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(ad + (uint32_t)(p * 256));
-                    b1 += v.x;
-                    b2 += v.y;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sh), "s"(0x78u), "v"(gb));
+                    v[p] = *(lds_cf2v *)(uintptr_t)(ad + (uint32_t)(p * 128));
+                }
+#pragma unroll
+                for (int p = 0; p < 8; p += 2) {
+                    acc += v[p];
+                    acc1 += v[p + 1];
                 }
             } else {
                 for (int p = 0; p < NPAIR - 8 * g; ++p) {
-                    const uint32_t off = ((zs >> (4 * p)) & 15u) << 4;
-                    const fcd_d2v v = *(lds_cd2v *)(uintptr_t)(off + gb + (uint32_t)(p * 256));
-                    b1 += v.x;
-                    b2 += v.y;
+                    const uint32_t off = ((zs >> (4 * p)) & 15u) << 3;
+                    acc += *(lds_cf2v *)(uintptr_t)(off + gb + (uint32_t)(p * 128));
                 }
             }
             rn_c = rn_n;
             rm_c = rm_n;
         }
-        b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
-        b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+        acc += acc1;
+        const float4 ek = edge_k[e];
         if (e == 0 || (c & 3) == 0) rnd = fcd_philox((uint32_t)(c >> 2), chain, sweep, FCD_KIND_F, k0, k1);
-        const double x = fcd_u32(fcd_word(rnd, (int)(c & 3)));
+        const uint32_t xw = fcd_word(rnd, (int)(c & 3));
         bool amb;
-        int k = fcd_draw_f_fast(0.0, b1, b2, x, margin, &amb);
-        if (__ballot(amb) != 0ull) k = fcd_draw_f(0.0, b1, b2, x);  // too close to a boundary somewhere in the wave
+        int k = fcd_draw_f_fast32(ek.x + acc.x, ek.y + acc.y, (float)xw * 2.3283064e-10f, ek.z, margin, &amb);
+        if (__ballot(amb) != 0ull) {
+            // somewhere in the wave the fp32 sums cannot decide the draw: the edge again, in fp64, for the whole wave
+            bool first = true;
+            double b1 = 0.0, b2 = 0.0;
+            const double *row = lMf + c * U * 6;
+#pragma unroll 1
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t a_ = ru[(uint32_t)((wn * NW16 + g) * 64) + ul], b_ = ru[(uint32_t)((wm * NW16 + g) * 64) + ul];
+                fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), (a_ ^ b_) | ((a_ & b_) << 2), first, b1, b2);
+            }
+            b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
+            b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
+            k = fcd_draw_f(0.0, b1, b2, fcd_u32(xw));
+            if (lane == 0) atomicAdd(dbg, 1ull);
+        }
         (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
         if (fsq) {
             uint8_t *sq = fsq + (int64_t)w * Nreg * Nreg * 64;
@@ -998,21 +1118,21 @@ static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int
     f_plan p = {F_GENERIC, (int)((U + 15) / 16), 0, 0, (int)((U + 15) / 16)};
     if (!have_lMf || (size_t)U * 48 > 160 * 1024) return p;
     const bool words_ok = GW * Nreg * p.NW16 < INT32_MAX / 4;       // r_U item index in 32 bits
-    const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 256 + (size_t)FP_EC * U * 48;
+    const size_t pair_shmem = (size_t)FP_EC * ((U + 1) / 2) * 128 + FP_EC * 16 + (size_t)FP_EC * U * 48;   // fp32 records, edge constants, fp64 rows
     if (f_form != F_PAIRX && f_form != F_DIFF && p.NW16 <= 4 && pair_shmem <= 96 * 1024 && words_ok) {
         p.form = F_PAIR;
         p.EC = FP_EC;
         p.shmem = pair_shmem;
         return p;
     }
-    const size_t per_edge = (size_t)((U + 1) / 2) * 256;
-    if (f_form != F_DIFF && words_ok && per_edge + 16 * 48 * 16 <= 160 * 1024) {
+    const size_t per_edge = (size_t)((U + 1) / 2) * 128, extra = 128 + 16 * 48 * 16;   // fp32 records; edge constants + a 768-byte staging scratch per wave
+    if (f_form != F_DIFF && words_ok && per_edge + extra <= 160 * 1024) {
         // largest tile that still lets two workgroups share a CU; one edge per tile may take the whole LDS
         int ec = 8;
-        while (ec > 1 && (size_t)ec * per_edge + 16 * 48 * 16 > 80 * 1024) ec >>= 1;
+        while (ec > 1 && (size_t)ec * per_edge + extra > 80 * 1024) ec >>= 1;
         p.form = F_PAIRX;
         p.EC = ec;
-        p.shmem = (size_t)ec * per_edge + 16 * 48 * 16;      // + a 768-byte staging scratch per wave
+        p.shmem = (size_t)ec * per_edge + extra;
         return p;
     }
     p.form = F_DIFF;
@@ -1064,7 +1184,7 @@ int fcd_gibbs_f_step_sq(fcd_ctx *ctx, const double *S_B, const double *lM, const
             FCD_LAUNCH_CHECK();
         }
         dim3 grid((unsigned)((g.C + pl.EC - 1) / pl.EC), (unsigned)((g.GW + wpb - 1) / wpb));
-#define FCD_F_ARGS S_B, lMf, hyper, f_state, r_U, (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq
+#define FCD_F_ARGS S_B, lMf, hyper, f_state, r_U, (int)Nreg, (int)U, g.C, g.GW, (uint32_t)chain0, seed, (uint32_t)sweep, margin, fsq, (unsigned long long *)ctx->dbg
 #define FCD_LAUNCH_F(KERN, SLOT)                                                                              \
     do {                                                                                                      \
         rc = fcd_lds_attr(ctx, SLOT, reinterpret_cast<const void *>(&KERN), pl.shmem);                        \
