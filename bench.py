@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--mstep-lag", default="auto", choices=["auto", "0", "1"],
                     help="1: the M-step of sweep s is applied after sweep s+1, its all-reduce overlaps that sweep "
                          "(auto: 1 with several ranks, 0 with one)")
+    ap.add_argument("--collective", default="direct", choices=["direct", "torch"],
+                    help="several ranks: 'direct' = the library's own RCCL communicator, ncclAllReduce of the pooled counts queued "
+                         "on the stream of the sweep kernels inside fcd_gibbs_run (round 4); 'torch' = round 3's loop through "
+                         "torch.distributed (counts -> all_reduce on its stream -> fcd_gibbs_mstep)")
     ap.add_argument("--force-pg", action="store_true",
                     help="one rank only: initialise an RCCL process group of ONE rank anyway and run the several-rank loop "
                          "(counts -> all-reduce -> fcd_gibbs_mstep, lagged schedule) on it: what an 8-GPU run does, on one GPU")
@@ -94,7 +98,8 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     ranks_seen = dist.get_world_size() if use_pg else 1
-    lag = (1 if use_pg else 0) if args.mstep_lag == "auto" else int(args.mstep_lag)
+    direct = args.collective == "direct"
+    lag = (1 if (use_pg and not direct) else 0) if args.mstep_lag == "auto" else int(args.mstep_lag)
 
     import fcdiff_amd
     from fcdiff_amd.gibbs import GibbsEngine, run_chains
@@ -149,12 +154,12 @@ def main():
     # ---- timed region: W warm-up steps, then exactly K steps of the sampler loop ----
     s_w = args.settle                                                     # first warm-up sweep
     if args.settle > 0:
-        run_chains(eng, args.settle, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
-    run_chains(eng, args.warmup, sweep0=s_w, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
+        run_chains(eng, args.settle, sweep0=0, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg, direct=direct)
+    run_chains(eng, args.warmup, sweep0=s_w, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg, direct=direct)
     fence()
     n_alloc0 = ctx.stat("n_alloc")
     t0 = time.perf_counter()
-    run_chains(eng, args.steps, sweep0=s_w + args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg)
+    run_chains(eng, args.steps, sweep0=s_w + args.warmup, mstep_every=args.mstep_every, burn_in=0, mstep_lag=lag, force_collective=use_pg, direct=direct)
     fence()
     elapsed = time.perf_counter() - t0
     allocs_in_timed_region = ctx.stat("n_alloc") - n_alloc0
@@ -181,6 +186,16 @@ def main():
             dist.all_reduce(cts)
         torch.cuda.synchronize()
         allreduce_us = (time.perf_counter() - ta) / 50 * 1e6
+        if ctx.stat("comm_world"):              # the library's own communicator: the same 8 words, queued on the compute stream
+            from fcdiff_amd import _lib as _L
+            for _ in range(5):
+                ctx.call("fcd_allreduce_stats", _L.dptr(cts), _L.stream_ptr())
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(50):
+                ctx.call("fcd_allreduce_stats", _L.dptr(cts), _L.stream_ptr())
+            torch.cuda.synchronize()
+            allreduce_us = (time.perf_counter() - ta) / 50 * 1e6
 
     # ---- per-kernel durations: one HIP event pair around EVERY f / step / pack launch costs ~3.7 us per event
     # (30+ per sweep), which would slow the timed region by ~20 %; so the same K steps are run once more right after it,
@@ -291,6 +306,9 @@ def main():
                    "chains_per_gpu": G, "chains_total": world * G, "edge_index": "symmetric",
                    "mstep_lag": lag, "ranks_seen": ranks_seen, "allreduce_us": allreduce_us,
                    "process_group": ("nccl, %d rank(s)%s" % (ranks_seen, ", forced" if (args.force_pg and world == 1) else "")) if use_pg else None,
+                   "collective": (("library-owned RCCL communicator: ncclAllReduce(8 x int64) on the stream of the sweep kernels, inside fcd_gibbs_run"
+                                   if (direct and not lag) else "torch.distributed all_reduce on the collective's stream + fcd_gibbs_mstep") if use_pg else None),
+                   "comm_world": ctx.stat("comm_world"),
                    "rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms), "r_pass_form": r_form,
                    "settle_sweeps": args.settle,     # untimed, before the W warm-up steps (burn-in; device steady state)
                    "sample_definition": "one sweep of one chain = C f-draws + Nreg*U r-draws"},

@@ -17,10 +17,12 @@ FCD_ERR_SHAPE = -2
 FCD_ERR_UNSUPPORTED = -3
 FCD_ERR_INDEX = -4
 FCD_ERR_DEVICE = -5
+FCD_ERR_COMM = -6
+FCD_COMM_ID_BYTES = 128
 EDGE_REFERENCE = 0
 EDGE_SYMMETRIC = 1
 EDGE_MODES = {"reference": EDGE_REFERENCE, "symmetric": EDGE_SYMMETRIC}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -40,6 +42,11 @@ SIGNATURES = {
     "fcd_ctx_stat": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "fcd_ctx_check": (_int, [_p]),
     "fcd_ctx_clear_error": (_int, [_p]),
+    "fcd_comm_load": (_int, [_p, C.c_char_p]),
+    "fcd_comm_unique_id": (_int, [_p, _p]),
+    "fcd_comm_init": (_int, [_p, _p, _int, _int]),
+    "fcd_comm_destroy": (_int, [_p]),
+    "fcd_allreduce_stats": (_int, [_p, _p, _p]),
     "fcd_prof_enable": (_int, [_p, _int]),
     "fcd_prof_collect": (_int, [_p, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     "fcd_N_to_C": (_i64, [_i64]),
@@ -125,7 +132,7 @@ def check(rc, ctx=None):
         raise IndexError(text)
     if rc == FCD_ERR_UNSUPPORTED:
         raise NotImplementedError(text)
-    if rc == FCD_ERR_DEVICE:
+    if rc == FCD_ERR_DEVICE or rc == FCD_ERR_COMM:
         raise FcdiffHipError(text)
     raise FcdiffHipError("HIP error %d: %s %s" % (rc, base, msg))
 
@@ -176,6 +183,39 @@ class Context(object):
 
     def clear_error(self):
         self.call("fcd_ctx_clear_error")
+
+    def attach_comm(self, group=None):
+        """
+        Give this context an RCCL communicator over the ranks of the torch.distributed `group` (default: the world):
+        from then on fcd_gibbs_run pools the counts of every M-step over those ranks with ncclAllReduce on the stream of
+        the sweep kernels (include/fcdiff_hip.h, fcd_comm_*).  Collective: every rank of the group calls it, before any
+        sweep.  The unique id travels through the group itself (a 128-byte broadcast from its rank 0); RCCL's entry
+        points come from the librccl torch has loaded.  A group of one rank is legal.
+        """
+        import os
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        if self.stat("comm_world"):
+            return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("attach_comm needs an initialised torch.distributed process group")
+        (world, rank) = (dist.get_world_size(group), dist.get_rank(group))
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.call("fcd_comm_load", path.encode() if os.path.exists(path) else b"")
+        ident = np.zeros(FCD_COMM_ID_BYTES, dtype=np.uint8)
+        if rank == 0:
+            self.call("fcd_comm_unique_id", ident.ctypes.data_as(_p))
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.from_numpy(ident).to(self.device) if on_gpu else torch.from_numpy(ident)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        ident = np.ascontiguousarray(t.cpu().numpy())
+        torch.cuda.synchronize()
+        self.call("fcd_comm_init", ident.ctypes.data_as(_p), int(world), int(rank))
+
+    def detach_comm(self):
+        self.call("fcd_comm_destroy")
 
     PROF_SLOTS = {"lik_kernel": 0, "gibbs_f_pair_kernel": 1, "gibbs_r_step_kernel": 2, "pack_f_kernel": 3}
 

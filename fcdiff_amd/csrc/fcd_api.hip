@@ -115,6 +115,7 @@ const char *fcd_strerror(int code) {
         case FCD_ERR_UNSUPPORTED: return "shape outside what the gfx950 kernels are built for";
         case FCD_ERR_INDEX: return "reference edge id out of range";
         case FCD_ERR_DEVICE: return "a kernel abandoned a device-side wait; the chain state is unusable";
+        case FCD_ERR_COMM: return "RCCL: library not found or a call failed";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -142,6 +143,9 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->fsq_bytes = 0;
     ctx->acc = nullptr;
     ctx->dbg = nullptr;
+    ctx->comm = nullptr;
+    ctx->comm_world = ctx->comm_rank = 0;
+    ctx->pool_counts = nullptr;
     ctx->corr_tickets = nullptr;
     ctx->corr_tickets_n = 0;
     ctx->prof_on = 0;
@@ -158,6 +162,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_ub = (int)knob_env("FCD_R_UB");
     ctx->knobs.r_nopad = (int)knob_env("FCD_R_NOPAD");
     ctx->knobs.r_dsplit = (int)knob_env("FCD_R_DSPLIT");
+    ctx->knobs.r_coop = (int)knob_env("FCD_R_COOP");
     ctx->knobs.r_refill = (int)knob_env("FCD_R_REFILL");
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
@@ -204,6 +209,8 @@ int fcd_ctx_create(fcd_ctx **out) {
 
 int fcd_ctx_destroy(fcd_ctx *ctx) {
     if (!ctx) return FCD_OK;
+    (void)fcd_comm_destroy(ctx);
+    if (ctx->pool_counts) (void)hipFree(ctx->pool_counts);
     hipError_t e = hipSuccess;
     if (ctx->ws) e = hipFree(ctx->ws);
     if (ctx->log_tab) (void)hipFree(ctx->log_tab);
@@ -241,6 +248,7 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_ub")) k.r_ub = (int)value;
     else if (!strcmp(name, "r_nopad")) k.r_nopad = (int)value;
     else if (!strcmp(name, "r_dsplit")) k.r_dsplit = (int)value;
+    else if (!strcmp(name, "r_coop")) k.r_coop = (int)value;
     else if (!strcmp(name, "r_refill")) k.r_refill = (int)value;
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;
@@ -275,6 +283,7 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out) {
     else if (!strcmp(name, "ws_bytes")) *out = (int64_t)ctx->ws_bytes;
     else if (!strcmp(name, "fsq_bytes")) *out = (int64_t)ctx->fsq_bytes;
     else if (!strcmp(name, "r_form_last")) *out = ctx->r_form_last;
+    else if (!strcmp(name, "comm_world")) *out = ctx->comm ? ctx->comm_world : 0;
     else if (!strcmp(name, "dev_err")) *out = ctx->dev_err ? (int64_t)*ctx->dev_err : 0;
     else if (!strcmp(name, "f_repeats") || !strcmp(name, "r_exact_rows")) {
         // event counters kept on the device (a synchronising read: diagnostics only)

@@ -22,6 +22,7 @@ struct fcd_knobs {
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups
     int r_refill;      // 1: the packing launch writes the panel-value sentinels in every sweep (default: only in the first sweep of a fcd_gibbs_run call)
+    int r_coop;        // pipelined r pass: 1 = cooperative launch (the runtime checks that the grid is co-resident; +16 us per pass), else plain
     int r_dsplit;      // 1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, where there are more than 8)
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit
     double f_tol;      // > default: the same for the f draws
@@ -50,6 +51,9 @@ struct fcd_ctx {
     void *log_tab;     // K_lik tables (fcd_fastmath.h): 64 x 2^(-j/64), 512 x {1/m_i, log m_i} (device, 8.5 KiB)
     volatile unsigned *dev_err;   // pinned host word: error word of the one-launch r pass, copied back after each pass
     void *acc;         // 8 x uint64, zero between launches: the tally's pooled sums [0..3] and its ticket [4]
+    void *comm;        // ncclComm_t of the context (fcd_comm_init), or nullptr: fcd_gibbs_run pools its M-step counts over it
+    int comm_world, comm_rank;
+    void *pool_counts; // 8 x int64 (device): the counts vector the all-reduce works on in place
     void *dbg;         // 8 x uint64 event counters (fcd_ctx_stat): [0] waves of the f pass that repeated an edge's sums in fp64,
                        // [1] rows of the r pass's in-order role decided on the exact path; never reset by the library
     void *corr_tickets;            // K_corr: one ticket per subject, zero between launches (the last taker resets it)
@@ -96,6 +100,7 @@ static inline int fcd_static_lds_check(fcd_ctx *ctx, const void *fn, int *done) 
     return FCD_OK;
 }
 
+int fcd_comm_allreduce_counts(fcd_ctx *ctx, long long *counts, hipStream_t stream);     // fcd_comm.hip: no-op without a communicator
 int fcd_ws_reserve(fcd_ctx *ctx, size_t bytes);
 // square copy of the f state (see fcd_gibbs_sweeps): grown like the workspace
 int fcd_fsq_reserve(fcd_ctx *ctx, size_t bytes);

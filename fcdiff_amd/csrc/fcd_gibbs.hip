@@ -1410,13 +1410,30 @@ extern "C" int fcd_gibbs_run(fcd_ctx *ctx, const double *S_B, const double *lM, 
         // the r pass's scratch is dead once its last launch is queued: the slot words of the next f pass go to its place
         uint32_t *r_U_next = (pair_form && !last) ? (uint32_t *)((char *)ctx->ws + ru_off) : nullptr;
         int64_t *cts = (last ? counts : nullptr);
+        // Several ranks (a communicator on the context): the tally leaves this rank's counts in the context's vector, RCCL sums
+        // it over the ranks in place ON THIS STREAM, a one-thread kernel makes the M-step from the pooled counts -- all queued
+        // behind one another, the host far ahead.  One rank: the M-step runs inside the tally launch.
+        const bool pooled = do_m && ctx->comm != nullptr;
+        int64_t *tally_counts = pooled ? (int64_t *)ctx->pool_counts : cts;
         if (do_m || do_a || cts || r_U_next) {
-            rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, cts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
-                              do_m ? hyper : nullptr, r_U_next, pl.NW, s, f_done);
+            rc = launch_tally(ctx, f_state, r_bits, Nreg, U, G, g, tally_counts, do_a ? cnt_f : nullptr, do_a ? cnt_r : nullptr,
+                              (do_m && !pooled) ? hyper : nullptr, r_U_next, pl.NW, s, f_done);
             if (rc) {
                 if (tf.acc) (void)hipMemsetAsync(ctx->acc, 0, 8 * sizeof(unsigned long long), s);
                 return rc;
             }
+        }
+        if (pooled) {
+            rc = fcd_comm_allreduce_counts(ctx, (long long *)ctx->pool_counts, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL(gibbs_mstep_kernel, dim3(1), dim3(1), 0, s, (const long long *)ctx->pool_counts, (double)(Nreg * U),
+                               (double)fcd_tri(Nreg), hyper);
+            FCD_LAUNCH_CHECK();
+            if (cts) FCD_HIP_TRY(hipMemcpyAsync(cts, ctx->pool_counts, 8 * sizeof(long long), hipMemcpyDeviceToDevice, s));
+        } else if (cts && ctx->comm) {
+            // (counts asked for without an M-step in this sweep: pooled all the same -- what a caller of several ranks expects)
+            rc = fcd_comm_allreduce_counts(ctx, (long long *)cts, s);
+            if (rc) return rc;
         }
         ru_ready = r_U_next != nullptr;
     }

@@ -1384,7 +1384,24 @@ int launch_pipe(fcd_ctx *ctx, const r_step_args &a, size_t shmem, bool *fits, bo
     *fits = (int64_t)ctx->pipe_occ[slot] * ctx->num_cu >= (int64_t)a.nD + a.nP + R_PIPE_SLOT_MARGIN;
     if (!*fits || !launch) return FCD_OK;
     fcd_prof_begin(ctx, FCD_PROF_RSTEP, s);
-    hipLaunchKernelGGL((gibbs_r_pipe_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), shmem, s, a, ctx->dev_err);
+    if (ctx->knobs.r_coop == 1) {
+        // a COOPERATIVE launch (knob r_coop = 1): the runtime itself refuses a grid that cannot be resident at once (the
+        // precondition of every device-side wait in the kernel) instead of this file's occupancy arithmetic being the only
+        // guard.  Not the default: measured 257.2 us per pass against 241.2 us with the plain launch
+        // (profiles/r04_coop_and_collective.txt) -- the runtime serialises a cooperative dispatch against its queue.
+        r_step_args ac = a;
+        volatile unsigned *errp = ctx->dev_err;
+        void *kargs[2] = {(void *)&ac, (void *)&errp};
+        hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), kargs, (unsigned)shmem, s);
+        if (e == hipErrorCooperativeLaunchTooLarge) {
+            (void)hipGetLastError();
+            *fits = false;                       // the caller falls back to one launch per block step
+            return FCD_OK;
+        }
+        if (e != hipSuccess) return (int)e;
+    } else {
+        hipLaunchKernelGGL((gibbs_r_pipe_kernel<UB, WPE>), dim3((unsigned)(a.nD + a.nP + a.npad)), dim3(threads), shmem, s, a, ctx->dev_err);
+    }
     fcd_prof_end(ctx, FCD_PROF_RSTEP, s);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
@@ -1581,7 +1598,11 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         if (ub == 4) rc = launch_pipe<4, 4>(ctx, a, shmem, &pipe, true, s);
         else if (ub == 2) rc = launch_pipe<2, 8>(ctx, a, shmem, &pipe, true, s);
         else rc = launch_pipe<1, 8>(ctx, a, shmem, &pipe, true, s);
-        return rc;
+        if (rc || pipe) return rc;
+        // the runtime refused the cooperative launch (grid not co-resident after all): the step-per-launch form instead
+        ctx->r_form_last = 1;
+        a.flags = nullptr;
+        a.dsplit = 0;
     }
     // one launch per block step: launch st = D(st-1) workgroups + P(st) workgroups
     for (int st = 0; st <= NBLK; ++st) {

@@ -234,7 +234,7 @@ def _world_size(group=None):
 
 
 def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_theta=True, group=None,
-               on_sweep=None, mstep_lag=0, force_collective=False):
+               on_sweep=None, mstep_lag=0, force_collective=False, direct=True):
     """
     The sampler loop shared by UnsharedRegionFit(method='gibbs') and bench.py.
 
@@ -247,6 +247,8 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
         The schedule -- and with it every chain's path -- is the same for any number of ranks, one rank included.
     `engine` is anything with run/mstep (the HIP engine here; the CPU tests pass an oracle-backed stand-in to
     exercise the multi-process logic under gloo).
+    direct=True (default; HIP engine, mstep_lag=0): several ranks pool their counts through the context's own RCCL
+    communicator INSIDE fcd_gibbs_run (Context.attach_comm); direct=False keeps round 3's loop through torch.distributed.
     force_collective=True takes the several-rank path -- counts, all-reduce, fcd_gibbs_mstep between calls -- also in a
     process group of ONE rank (bench.py --force-pg, tests/test_dist_nccl.py: RCCL initialised and used on a one-GPU box;
     the chains are those of the plain loop, bit for bit).
@@ -256,6 +258,12 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
     collective = world > 1 or (bool(force_collective) and dist.is_available() and dist.is_initialized())
     k = int(mstep_every) if (update_theta and mstep_every and mstep_every > 0) else 0
     acc_from = sweep0 + burn_in
+    if collective and direct and not mstep_lag and hasattr(engine, "ctx") and hasattr(engine.ctx, "attach_comm"):
+        # Round 4: the all-reduce of the pooled counts is RCCL called by the library itself on the stream of the sweep
+        # kernels (fcd_comm_*): the several-rank loop is then the one-rank loop -- ONE fcd_gibbs_run call per chunk, the
+        # tally, the all-reduce, the M-step kernel and the next f pass queued behind one another.
+        engine.ctx.attach_comm(group)
+        collective = False
     if not collective and on_sweep is None and not mstep_lag:
         engine.run(sweep0, n_sweeps, mstep_every=k, accumulate_from=acc_from)
         return

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FCD_ABI_VERSION 3
+#define FCD_ABI_VERSION 4
 
 #define FCD_OK 0
 #define FCD_ERR_ARG (-1)         /* null pointer / non-positive size */
@@ -50,6 +50,8 @@ extern "C" {
 #define FCD_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (message says which) */
 #define FCD_ERR_INDEX (-4)       /* reference edge ids run out of range (Nreg == 2, fit.py:186) */
 #define FCD_ERR_DEVICE (-5)      /* a kernel gave up a device-side wait (one-launch r pass); the chain state is unusable */
+#define FCD_ERR_COMM (-6)        /* RCCL: library not found, or a call failed (fcd_last_message says which) */
+#define FCD_COMM_ID_BYTES 128    /* sizeof(ncclUniqueId) */
 
 /* Edge id used by the region update for an ordered pair (n, m), m != n. */
 #define FCD_EDGE_REFERENCE 0 /* nm_to_c(n,m) = n(n-1)/2 + m for EVERY ordered pair, as fit.py:185-186 calls it */
@@ -73,7 +75,7 @@ int fcd_ctx_destroy(fcd_ctx *ctx);
 /* Sizes every scratch buffer of the sweep at this shape (f / r pass workspace, square f copy): after it no
  * sampler entry point allocates or synchronises at shapes up to (Nreg, U, G).  Synchronises when it grows something. */
 int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
-/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_REFILL, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
+/* Tuning / test knobs (defaults: environment FCD_R_PATH, FCD_R_UB, FCD_R_NOPAD, FCD_R_DSPLIT, FCD_R_COOP, FCD_R_REFILL, FCD_R_TOL, FCD_F_TOL, FCD_F_FORM,
  * FCD_CORR_FORM, read once by fcd_ctx_create; 0 = default everywhere; the two test hooks at the end of the list are NOT read
  * from the environment -- a stray variable must not be able to make a fit give up):
  *   "r_path"    0: blocked r pass in its pipelined one-launch form (marks / sentinels in device memory instead of
@@ -83,6 +85,9 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *   "r_nopad"   1: no empty workgroups beside the in-order workgroups
  *   "r_dsplit"  1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, on two CUs,
  *               where a group has more than 8 chain words and 2 U <= number of CUs)
+ *   "r_coop"    1: COOPERATIVE launch of the pipelined r pass -- the runtime itself checks that the grid is resident at once
+ *               and the pass falls back to one launch per block step if it refuses (measured +16 us per pass at cfg3, so
+ *               not the default; the default relies on the occupancy query, 8 spare slots and bounded polls)
  *   "r_refill"  1: the pipelined r pass's packing launch writes the panel-value sentinels in every sweep (default: only in the
  *               first sweep of a fcd_gibbs_run call -- a completed pass leaves every slot holding its sentinel again)
  *   "corr_form" 1: fcd_corr_edges in 64 x 64 blocks with a moments pass also where the one-workgroup-per-subject kernel
@@ -107,6 +112,25 @@ int fcd_ctx_stat(const fcd_ctx *ctx, const char *name, int64_t *out);
  * counts of the tally, K_corr's per-subject tickets) back to zero (it synchronises: an error-recovery call). */
 int fcd_ctx_check(fcd_ctx *ctx);
 int fcd_ctx_clear_error(fcd_ctx *ctx);
+
+/* ---- the one exchange between GPUs: pooled counts before a (pi, gamma) M-step --------------------------------------
+ * ("fcd_allreduce_stats(ncclComm_t, ...)"; the reference has no counterpart -- single process.)
+ * One process per GPU.  The communicator belongs to the context and is made ONCE, before any sweep:
+ *   fcd_comm_load(ctx, path)     take RCCL's entry points from the librccl the process already holds (path = the file the
+ *                                host framework loaded, e.g. <torch>/lib/librccl.so; NULL / "" tries librccl.so.1)
+ *   fcd_comm_unique_id(ctx, id)  rank 0: ncclGetUniqueId -> 128 bytes, broadcast to the other ranks by whatever the caller
+ *                                has (the Python mirror uses its torch.distributed group)
+ *   fcd_comm_init(ctx, id, world, rank)   every rank (collective): ncclCommInitRank
+ * From then on fcd_gibbs_run pools the counts of every M-step over the communicator's ranks with ncclAllReduce(8 x int64,
+ * sum) ON THE STREAM OF THE SWEEP KERNELS, between the tally and a one-thread M-step kernel: no copy of the counts, no
+ * event between streams, no host in the loop.  A communicator of one rank is legal (and tested on the one-GPU box).
+ * fcd_allreduce_stats does the same for a caller-owned counts vector (8 int64, device), e.g. after fcd_gibbs_stats.
+ * fcd_comm_destroy before fcd_ctx_destroy (which also calls it). */
+int fcd_comm_load(fcd_ctx *ctx, const char *librccl_path);
+int fcd_comm_unique_id(fcd_ctx *ctx, uint8_t *id128);
+int fcd_comm_init(fcd_ctx *ctx, const uint8_t *id128, int world, int rank);
+int fcd_comm_destroy(fcd_ctx *ctx);
+int fcd_allreduce_stats(fcd_ctx *ctx, int64_t *counts, fcd_stream stream);
 
 /* Optional timing of the library's main kernels with HIP events recorded on the launch stream, each pair
  * bracketing exactly ONE kernel launch.  slot: 0 likelihood tables, 1 f pass, 2 r block step (or one-launch pass), 3 r pack.

@@ -22,6 +22,8 @@ from fcdiff_amd.gibbs import GibbsEngine  # noqa: E402
 
 def main():
     (Nreg, H, U, G) = (200, 50, 50, 1024)
+    if len(sys.argv) >= 4:                       # e.g. `ablate.py 400 250 250` = the cfg5 share
+        (Nreg, H, U) = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
     model = fcdiff_amd.UnsharedRegionModel()
     (_r, _t, _f, _ft, b, bt) = model.sample_fast(Nreg, H, U, seed=0)
     fit = fcdiff_amd.fit.UnsharedRegionFit()
@@ -43,7 +45,7 @@ def main():
              ("r diag no-chain", "r", {"FCD_ABL_DIAG": "2"}), ("r diag prologue-only", "r", {"FCD_ABL_DIAG": "3"}),
              ("r panel staging-only + diag prologue-only", "r", {"FCD_ABL_PANEL": "3", "FCD_ABL_DIAG": "3"})]
     res = {name: [] for (name, _, _) in cases}
-    for rnd in range(5):
+    for rnd in range(5 if Nreg <= 200 else 2):
         for (name, which, env) in cases:
             for k in ("FCD_ABL_F", "FCD_ABL_PANEL", "FCD_ABL_DIAG"):
                 os.environ.pop(k, None)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(raw, name), "libfcdiff_hip.so does not export %s" % name
     lib = _lib.load()
-    assert lib.fcd_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.fcd_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_host_index_maps_match_util():
@@ -79,7 +79,7 @@ def test_error_codes_of_header_and_binding_agree():
     import re
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fcdiff_hip.h")).read()
     codes = dict(re.findall(r"#define (FCD_ERR_[A-Z]+) \((-\d+)\)", text))
-    assert set(codes) == {"FCD_ERR_ARG", "FCD_ERR_SHAPE", "FCD_ERR_UNSUPPORTED", "FCD_ERR_INDEX", "FCD_ERR_DEVICE"}
+    assert set(codes) == {"FCD_ERR_ARG", "FCD_ERR_SHAPE", "FCD_ERR_UNSUPPORTED", "FCD_ERR_INDEX", "FCD_ERR_DEVICE", "FCD_ERR_COMM"}
     lib = _lib.load()
     seen = set()
     for (name, val) in codes.items():

@@ -16,7 +16,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir, with_group=True, force=False):
+def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir, with_group=True, force=False, direct=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -41,7 +41,7 @@ def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir,
         eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], N, U, n_local, chain0=chain0, seed=seed, ctx=fit._context())
         eng.set_hyper(m.gamma, m.pi2())
         eng.init(0.2)
-        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=force)
+        run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=force, direct=direct)
         torch.cuda.synchronize()
         (f, r) = eng.export_state()
         cnt = eng.cnt_r.to(torch.int64).clone()
@@ -49,7 +49,7 @@ def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir,
             dist.all_reduce(cnt)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f=f, r=r, hyper=eng.hyper.cpu().numpy(), chain0=chain0,
                  cnt_r=cnt.cpu().numpy(), world=dist.get_world_size() if with_group else 0,
-                 r_form=eng.ctx.stat("r_form_last"))
+                 r_form=eng.ctx.stat("r_form_last"), comm_world=eng.ctx.stat("comm_world"))
     finally:
         if with_group:
             dist.destroy_process_group()
@@ -62,8 +62,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (2, 1)])
-def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag):
+@pytest.mark.parametrize("mstep_every,lag,direct", [(1, 0, True), (2, 0, True), (1, 0, False), (2, 1, False)])
+def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag, direct):
     import torch
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
@@ -75,7 +75,7 @@ def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag):
     two.mkdir()
     # children only: the parent never initialises the GPU
     mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(one)), nprocs=1, join=True)
-    mp.spawn(_worker, args=(2, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(two)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(two), True, False, direct), nprocs=2, join=True)
     ref = np.load(os.path.join(str(one), "rank0.npz"))
     parts = [np.load(os.path.join(str(two), "rank%d.npz" % r)) for r in range(2)]
     assert [int(p["world"]) for p in parts] == [2, 2] and [int(p["chain0"]) for p in parts] == [0, 96]
@@ -87,13 +87,17 @@ def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mstep_every,lag", [(1, 0), (1, 1), (2, 1)])
-def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag):
+@pytest.mark.parametrize("mstep_every,lag,direct", [(1, 0, True), (2, 0, True), (1, 0, False), (1, 1, False), (2, 1, False)])
+def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag, direct):
     """
     RCCL on the one GPU of the build box: a process group of ONE rank (backend nccl, initialised before anything touches
-    the GPU), and the several-rank loop forced on it -- counts, all-reduce (blocking, or asynchronous on the collective's
-    stream under the lagged schedule), work.wait(), fcd_gibbs_mstep -- beside the default pipelined r pass.  The chains,
-    the hyper-parameters and the marginal counters must equal those of the same schedule without any process group.
+    the GPU), and the several-rank loop forced on it, beside the default pipelined r pass --
+      direct=True   (round 4, the default): the library's own communicator (ncclGetUniqueId -> broadcast through the torch group
+                    -> ncclCommInitRank), ncclAllReduce of the pooled counts queued on the stream of the sweep kernels inside
+                    fcd_gibbs_run, then the one-thread M-step kernel;
+      direct=False  round 3's loop: counts, torch.distributed all-reduce (blocking, or asynchronous on the collective's stream
+                    under the lagged schedule), work.wait(), fcd_gibbs_mstep.
+    The chains, the hyper-parameters and the marginal counters must equal those of the same schedule without any process group.
     """
     import torch
     if not torch.cuda.is_available():
@@ -105,9 +109,10 @@ def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag):
     plain.mkdir()
     group.mkdir()
     mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(plain), False, False), nprocs=1, join=True)
-    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(group), True, True), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(group), True, True, direct), nprocs=1, join=True)
     a = np.load(os.path.join(str(plain), "rank0.npz"))
     b = np.load(os.path.join(str(group), "rank0.npz"))
     assert int(b["world"]) == 1 and int(b["r_form"]) == 2          # (the pipelined form ran beside the collective)
+    assert int(b["comm_world"]) == (1 if direct else 0)            # (the library's own communicator was the one used -- or not)
     for k in ("f", "r", "hyper", "cnt_r"):
         np.testing.assert_array_equal(a[k], b[k])

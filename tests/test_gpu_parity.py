@@ -909,6 +909,56 @@ def test_gibbs_cfg3_size_properties(env):
     nptest.assert_allclose(lj[:8], env.CO.gibbs_logjoint(f_g[:8].copy(), r_g[:8].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
 
 
+def test_fit_gibbs_cfg3_shape_end_to_end(env):
+    """
+    VERDICT r3 item 6b: the path bench.py times -- UnsharedRegionFit(method='gibbs').run() -> run_chains -> fcd_gibbs_run with
+    accumulation after burn-in and the (pi, gamma) M-step in every sweep's tally launch -- at BASELINE cfg 3's shape with all
+    1024 chains, against the C oracle walking the same chains with the host restatement of the M-step between sweeps:
+    final chain state, marginal counters (a recount from the oracle's chains), pi, gamma and the fit's log-marginals.
+    4 sweeps (1 burn-in): 4096 chain-sweeps of the oracle, what the suite's time budget allows.
+    """
+    from fcdiff_amd.gibbs import mstep_from_counts
+    (N, H, U, G, n_sweeps, burn) = (200, 50, 50, 1024, 4, 1)
+    gen = env.pkg.UnsharedRegionModel()
+    (_r, _t, _f, _ft, b, bt) = gen.sample_fast(N, H, U, seed=21)
+    fit = new_fit(env)
+    fit.model, fit.b, fit.bt = env.pkg.UnsharedRegionModel(), b, bt
+    fit.method, fit.n_chains, fit.n_sweeps, fit.burn_in, fit.mstep_every, fit.seed = "gibbs", G, n_sweeps, burn, 1, 77
+    m0 = env.pkg.UnsharedRegionModel()
+    fit.run()
+    assert env.ctx.stat("r_form_last") == 2 and env.ctx.stat("dev_err") == 0
+    # the oracle's side
+    S_B, lM = env.CO.lik_tables(b, bt, m0.theta())
+    (gamma, pi) = (np.asarray(m0.gamma, dtype=np.float64), float(m0.pi))
+    f_o, r_o = env.CO.gibbs_init(G, N, U, pi, 77, 0)
+    C = N * (N - 1) // 2
+    cf = np.zeros((C, 3), dtype=np.int64)
+    cr = np.zeros((N, U), dtype=np.int64)
+    for s_ in range(n_sweeps):
+        env.CO.gibbs_f_step(f_o, r_o, S_B, lM, np.log(gamma), 77, s_, 0)
+        env.CO.gibbs_r_step(f_o, r_o, lM, np.log(np.array([1.0 - pi, pi])), 77, s_, env.lib.EDGE_MODES["symmetric"], 0)
+        if s_ >= burn:
+            for k in range(3):
+                cf[:, k] += (f_o == k).sum(axis=0)
+            cr += r_o.sum(axis=0, dtype=np.int64)
+        counts = [int(r_o.sum())] + [int((f_o == k).sum()) for k in range(3)] + [G]
+        (pi, gamma) = mstep_from_counts(counts, N, U)
+    eng = fit.sampler
+    (f_g, r_g) = eng.export_state()
+    nptest.assert_array_equal(f_g, f_o)
+    nptest.assert_array_equal(r_g, r_o)
+    nptest.assert_array_equal(eng.cnt_f.cpu().numpy(), cf)
+    nptest.assert_array_equal(eng.cnt_r.cpu().numpy(), cr)
+    assert eng.n_accumulated == n_sweeps - burn
+    nptest.assert_allclose(fit.model.pi, pi, rtol=1e-14)
+    nptest.assert_allclose(fit.model.gamma, gamma, rtol=1e-14)
+    total = float((n_sweeps - burn) * G)
+    with np.errstate(divide="ignore"):
+        nptest.assert_array_equal(fit._lq_F, np.log(cf.reshape(C, 1, 3) / total))
+        p1 = cr / total
+        nptest.assert_array_equal(fit._lq_R, np.log(np.stack([1.0 - p1, p1], axis=2)))
+
+
 @pytest.mark.parametrize("N,U,G", [(40, 6, 1024), (97, 5, 320), (33, 9, 64)])
 def test_gibbs_run_keeps_the_sentinels_between_sweeps(env, knobs, N, U, G):
     """
@@ -1038,6 +1088,25 @@ def test_corr_cfg3_size(env):
     exp = env.O.corr_edges(ts)
     assert got.shape == (N * (N - 1) // 2, S)
     nptest.assert_allclose(got, exp, rtol=1e-11, atol=1e-13)
+
+
+def test_corr_cfg5_size(env):
+    """
+    The block kernel (64 x 64 blocks + moments pass: Nreg = 400 > 208) at BASELINE cfg 5's full size -- S = 500 subjects,
+    Nreg = 400, T = 1200, 1.92 GB of series, 79 800 x 500 correlations -- against numpy.corrcoef, subject by subject
+    (the bench timed this shape unchecked).  Oracle third-party: parity unpinned by the reference.
+    """
+    from fcdiff_amd.corr import correlations
+    (S, N, T) = (500, 400, 1200)
+    rs = np.random.RandomState(5)
+    ts = rs.standard_normal((S, N, T))
+    ts += 0.5 * rs.standard_normal((S, 1, T))
+    ts[:, 7, :] += 300.0                                      # a region far from zero mean
+    got = correlations(ts, ctx=env.ctx)
+    assert got.shape == (N * (N - 1) // 2, S)
+    for s_ in range(S):
+        exp = env.O.corr_edges(ts[s_:s_ + 1])
+        nptest.assert_allclose(got[:, s_:s_ + 1], exp, rtol=1e-11, atol=1e-13, err_msg="subject %d" % s_)
 
 
 def test_corr_both_kernels(env, knobs):
