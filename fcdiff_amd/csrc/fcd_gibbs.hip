@@ -239,6 +239,12 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
 // then the slot number of every pair at once, and a term costs two integer instructions for its address.
 // ---------------------------------------------------------------------------------------------
 // One slot-source word of (w, n): 16 patients in 4-bit fields (the pair (u, u+1) in the low two bits of field u/2).
+// Where slot word jw of (w, n) = wn lives for lane: the words of a region are kept FOUR side by side per lane (round 4), so
+// that one 16-byte load fetches what four 4-byte loads did -- a vector-memory instruction occupies the CU's address unit
+// for the same ~16 cycles whatever its width (profiles/r04_ubench_vmem_rate.txt), and the pair kernel issued eight per edge.
+__host__ __device__ static inline int64_t ru_index(int64_t wn, int NW, int jw, int lane) {
+    return ((wn * ((NW + 3) >> 2) + (jw >> 2)) * 64 + lane) * 4 + (jw & 3);
+}
 __device__ __forceinline__ uint32_t pack_ru_word(const uint64_t *__restrict__ r_bits, int64_t wn, int U, int jw, int lane) {
     uint32_t v = 0;
 #pragma unroll
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void pack_ru_kernel(const uint64_t *__restrict
     const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));      // (w, n, word): scalar
     if (item >= GW * Nreg * NW) return;
     const int jw = item % NW, wn = item / NW;                   // wn = w*Nreg + n
-    r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, lane);
+    r_U[ru_index(wn, NW, jw, lane)] = pack_ru_word(r_bits, wn, U, jw, lane);
 }
 
 constexpr int FP_EC = 8;     // edges per tile
@@ -314,14 +320,19 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     uint32_t Zc[NW16], rn[NW16];
     int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
     fcd_edge_to_pair(c0, wn, wm);
-    // wave-uniform base + unsigned 32-bit (region, lane) offset: no per-lane 64-bit address arithmetic
-    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * NW16 * 64;
+    // wave-uniform base + unsigned 32-bit (region, lane) offset: no per-lane 64-bit address arithmetic.  The (up to four)
+    // slot words of a region are ONE 16-byte load (ru_index).
+    const uint4 *__restrict__ ru = reinterpret_cast<const uint4 *>(r_U) + (int64_t)(w < GW ? w : 0) * Nreg * 64;
     const uint32_t ul = (uint32_t)lane;
+    auto comp = [](const uint4 &v, int j) -> uint32_t { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+    {
+        const uint4 vn = ru[(uint32_t)(wn * 64) + ul], vm = ru[(uint32_t)(wm * 64) + ul];
 #pragma unroll
-    for (int j = 0; j < NW16; ++j) {
-        rn[j] = ru[(uint32_t)((wn * NW16 + j) * 64) + ul];
-        const uint32_t rm = ru[(uint32_t)((wm * NW16 + j) * 64) + ul];
-        Zc[j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
+        for (int j = 0; j < NW16; ++j) {
+            rn[j] = comp(vn, j);
+            const uint32_t rm = comp(vm, j);
+            Zc[j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
+        }
     }
     {
         // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
@@ -413,13 +424,12 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 nm = 0;
                 nn = (nn + 1 < Nreg) ? nn + 1 : nn;
             }
-            uint32_t rnn[NW16], rmn[NW16];
+            // the next edge's words: region m always, region n only where the row of the triangle changes (wave-uniform)
+            uint4 vmn = make_uint4(0u, 0u, 0u, 0u), vnn = vmn;
+            const bool new_row = nn != wn;
             if (e + 1 < FP_EC) {
-#pragma unroll
-                for (int j = 0; j < NW16; ++j) {
-                    rnn[j] = ru[(uint32_t)((nn * NW16 + j) * 64) + ul];
-                    rmn[j] = ru[(uint32_t)((nm * NW16 + j) * 64) + ul];
-                }
+                vmn = ru[(uint32_t)(nm * 64) + ul];
+                if (new_row) vnn = ru[(uint32_t)(nn * 64) + ul];
             }
             fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds, none waits for the one before
 #pragma unroll
@@ -490,8 +500,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             if (e + 1 < FP_EC) {
 #pragma unroll
                 for (int j = 0; j < NW16; ++j) {
-                    rn[j] = rnn[j];
-                    Zc[j] = (rnn[j] ^ rmn[j]) | ((rnn[j] & rmn[j]) << 2);
+                    if (new_row) rn[j] = comp(vnn, j);
+                    const uint32_t rm = comp(vmn, j);
+                    Zc[j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
                 }
                 wn = nn;
                 wm = nm;
@@ -526,10 +537,13 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
     fcd_edge_to_pair(c0, wn, wm);
-    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * NW16 * 64;
+    // slot words: four groups of 16 patients side by side per lane (ru_index): one 16-byte load per region and four groups
+    const int NQ = (NW16 + 3) >> 2;
+    const uint4 *__restrict__ ru = reinterpret_cast<const uint4 *>(r_U) + (int64_t)(w < GW ? w : 0) * Nreg * NQ * 64;
     const uint32_t ul = (uint32_t)lane;
-    // slot words of the first group of the first edge: requested before the build so that their latency hides behind it
-    uint32_t rn_c = ru[(uint32_t)((wn * NW16) * 64) + ul], rm_c = ru[(uint32_t)((wm * NW16) * 64) + ul];
+    auto comp = [](const uint4 &v, int j) -> uint32_t { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+    // slot words of the first four groups of the first edge: requested before the build so that their latency hides behind it
+    uint4 rn_q = ru[(uint32_t)((wn * NQ) * 64) + ul], rm_q = ru[(uint32_t)((wm * NQ) * 64) + ul];
     float4 *edge_k = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ptile) + (size_t)EC * NPAIR * 128);   // [8]
     if (threadIdx.x < EC) edge_k[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -635,11 +649,16 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
         }
         const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 128));
         fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds
+        uint4 rn_n = rn_q, rm_n = rm_q;
         for (int g = 0; g < NG; ++g) {
-            // slot words of the next group (of the next edge after the last group): always loaded, from a valid place
-            const bool last = g + 1 == NG;
-            const int pn = last ? nn : wn, pm = last ? nm : wm, pg = last ? 0 : g + 1;
-            const uint32_t rn_n = ru[(uint32_t)((pn * NW16 + pg) * 64) + ul], rm_n = ru[(uint32_t)((pm * NW16 + pg) * 64) + ul];
+            // slot words of the next FOUR groups (of the next edge after the last): loaded at every fourth group, from a valid place
+            if ((g & 3) == 0) {
+                const bool last = (g >> 2) + 1 >= NQ;
+                const int pn = last ? nn : wn, pm = last ? nm : wm, pq = last ? 0 : (g >> 2) + 1;
+                rn_n = ru[(uint32_t)((pn * NQ + pq) * 64) + ul];
+                rm_n = ru[(uint32_t)((pm * NQ + pq) * 64) + ul];
+            }
+            const uint32_t rn_c = comp(rn_q, g & 3), rm_c = comp(rm_q, g & 3);
             const uint32_t zs = (rn_c ^ rm_c) | ((rn_c & rm_c) << 2);
             const uint32_t gb = tb + (uint32_t)(g * (8 * 128));
             if (NPAIR - 8 * g >= 8) {
@@ -662,8 +681,10 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                     acc += *(lds_cf2v *)(uintptr_t)(off + gb + (uint32_t)(p * 128));
                 }
             }
-            rn_c = rn_n;
-            rm_c = rm_n;
+            if ((g & 3) == 3 || g + 1 == NG) {
+                rn_q = rn_n;
+                rm_q = rm_n;
+            }
         }
         acc += acc1;
         const float4 ek = edge_k[e];
@@ -678,7 +699,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
             const double *row = lMf + c * U * 6;
 #pragma unroll 1
             for (int g = 0; g < NG; ++g) {
-                const uint32_t a_ = ru[(uint32_t)((wn * NW16 + g) * 64) + ul], b_ = ru[(uint32_t)((wm * NW16 + g) * 64) + ul];
+                const uint32_t a_ = comp(ru[(uint32_t)((wn * NQ + (g >> 2)) * 64) + ul], g & 3), b_ = comp(ru[(uint32_t)((wm * NQ + (g >> 2)) * 64) + ul], g & 3);
                 fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), (a_ ^ b_) | ((a_ & b_) << 2), first, b1, b2);
             }
             b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(1024) void gibbs_tally_kernel(const tally_args a) {
         const int items = GW * a.Nreg * NW;
         for (int item = ((int)blockIdx.x - nrb) * 16 + wave; item < items; item += ((int)gridDim.x - nrb) * 16) {
             const int jw = item % NW, wn = item / NW;                   // wn = w*Nreg + n
-            a.r_U[(int64_t)item * 64 + lane] = pack_ru_word(r_bits, wn, U, jw, lane);
+            a.r_U[ru_index(wn, NW, jw, lane)] = pack_ru_word(r_bits, wn, U, jw, lane);
         }
     }
     if (!a.acc) return;
@@ -1147,7 +1168,8 @@ static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int
 
 size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW) {
     // per-lane slot words r_U of the pair forms (the largest user; the other forms need nothing): 16 patients per word
-    return (size_t)GW * Nreg * ((U + 15) / 16) * 64 * sizeof(uint32_t);
+    // (four words side by side per lane: ru_index)
+    return (size_t)GW * Nreg * (((U + 15) / 16 + 3) / 4) * 64 * 4 * sizeof(uint32_t);
 }
 
 size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {
