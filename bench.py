@@ -246,7 +246,7 @@ def main():
         # HBM traffic of that kernel: NOT measured in this run (PMC passes cannot run beside the timed region) -- read from
         # the summary of two rocprofv3 --pmc passes of this same command committed under profiles/ (pmc_traffic.py)
         traffic = traffic_raw = traffic_src = None
-        for tname in ("r03_pmc_traffic_%s.json" % cfg_key, "r02_pmc_traffic_%s.json" % cfg_key):
+        for tname in ("r04_pmc_traffic_%s.json" % cfg_key, "r03_pmc_traffic_%s.json" % cfg_key, "r02_pmc_traffic_%s.json" % cfg_key):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
@@ -278,7 +278,7 @@ def main():
     lds_peak = n_cu * LDS_BYTES_PER_CLK_CU * LDS_CLOCK_GHZ / 1e3                                   # TB/s
     nblk = (Nreg + 15) // 16
     gw = (G + 63) // 64
-    f_lds = C * gw * ((U + 1) // 2) * 64 * 16                                     # one ds_read_b128 per (edge, word, patient pair)
+    f_lds = C * gw * ((U + 1) // 2) * 64 * 8                                      # one ds_read_b64 per (edge, word, patient pair): fp32 pair records (round 4)
     r_lds_pass = gw * U * Nreg * nblk * 8 * 64 * 8                                # one ds_read_b64 per (region, patient, word, pair of regions)
     lds = {"unit": "TB/s", "peak": lds_peak}
     if f_name in kern:
@@ -286,6 +286,34 @@ def main():
     if r_name in kern:
         lds[r_name] = r_lds_pass / n_step / (kern[r_name]["avg_launch_ms"] * 1e-3) / 1e12
     lds["frac"] = {k: lds[k] / lds_peak for k in (f_name, r_name) if k in lds}
+
+    # The bound that binds these two kernels is vector-instruction ISSUE, not bytes: SQ_INSTS_VALU per launch
+    # from the committed counter pass of this same command (profiles/pmc_lds_summary.py -> JSON), priced at 2 cycles of a SIMD
+    # per wave-instruction for two-source 32-bit work and 4 for fp64 / packed-fp32 / three-source / compare / select
+    # (profiles/r03_ubench_valu_rate.txt: 1.42 against 2.44 issue units), the share of the 4-cycle class counted in the
+    # kernel's ISA (profiles/r04_valu_mix.json, made by profiles/valu_mix.py from fcd_gibbs*.s), against the kernel's duration
+    # measured in THIS run: frac = 1 would be a kernel whose SIMDs issue a vector instruction in every slot.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "r04_pmc_lds_%s.json" % cfg_key)
+    mpath = os.path.join(ROOT, "profiles", "r04_valu_mix.json")
+    if os.path.exists(vpath):
+        try:
+            rec = json.load(open(vpath))
+            mix = json.load(open(mpath)) if os.path.exists(mpath) else {}
+            clock_hz = 2.4e9          # hipDeviceProp_t::clockRate of the box (printed by profiles/micro/vmem_rate: 2.40 GHz); torch does not expose it
+            n_simd = 4 * n_cu
+            valu = {"unit": "fraction of the SIMDs' issue slots", "source": "profiles/r04_pmc_lds_%s.json" % cfg_key,
+                    "mix_source": "profiles/r04_valu_mix.json" if mix else None, "clock_GHz": clock_hz * 1e-9,
+                    "note": "SQ_INSTS_VALU from an earlier profiled run of the same command, kernel time from this run"}
+            for k in (f_name, r_name):
+                if k in kern and k in rec:
+                    insts = rec[k]["per_launch"].get("SQ_INSTS_VALU")
+                    wide = float(mix.get(k, {}).get("frac_4_cycle", 0.5))
+                    cyc = insts * (2.0 + 2.0 * wide) / n_simd
+                    valu[k] = {"insts_valu_per_launch": insts, "frac_4_cycle_class": wide, "issue_cycles_per_simd": cyc,
+                               "frac": cyc / (kern[k]["avg_launch_ms"] * 1e-3 * clock_hz)}
+        except Exception as exc:      # (a malformed summary must not cost the bench line)
+            valu = {"error": str(exc)}
 
     sweep_bytes = 2 * 72 * C * U + 24 * C + G * (2 * C + 3 * Nreg * U)            # per sweep of G chains
     out = {
@@ -317,6 +345,7 @@ def main():
                       "frac_of_peak": sweep_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         "kernels": kern,
         "lds_roofline": lds,
+        "roofline_valu": valu,
         "passes_ms": {"f_pass": f_pass_ms, "r_pass": r_pass_ms, "tally": tally_ms,
                       "f_pass_GBps": f_bytes / (f_pass_ms * 1e-3) / 1e9, "r_pass_GBps": r_bytes / (r_pass_ms * 1e-3) / 1e9,
                       "f64_adds_per_s": (2 * C * U * G + 2 * C * U * G) / ((f_pass_ms + r_pass_ms) * 1e-3)},

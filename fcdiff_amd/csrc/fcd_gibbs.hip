@@ -242,8 +242,10 @@ __global__ __launch_bounds__(1024) void gibbs_f_diff_kernel(const double *__rest
 // Where slot word jw of (w, n) = wn lives for lane: the words of a region are kept FOUR side by side per lane (round 4), so
 // that one 16-byte load fetches what four 4-byte loads did -- a vector-memory instruction occupies the CU's address unit
 // for the same ~16 cycles whatever its width (profiles/r04_ubench_vmem_rate.txt), and the pair kernel issued eight per edge.
+// (NW <= 4, the U <= 64 kernel: side by side.  The any-U kernel consumes one word per loop turn and keeps [word][lane]: with
+// the 16-byte words held across four turns it measured 1.83 against 1.72 ms at cfg5.)
 __host__ __device__ static inline int64_t ru_index(int64_t wn, int NW, int jw, int lane) {
-    return ((wn * ((NW + 3) >> 2) + (jw >> 2)) * 64 + lane) * 4 + (jw & 3);
+    return NW <= 4 ? (wn * 64 + lane) * 4 + jw : (wn * NW + jw) * 64 + lane;
 }
 __device__ __forceinline__ uint32_t pack_ru_word(const uint64_t *__restrict__ r_bits, int64_t wn, int U, int jw, int lane) {
     uint32_t v = 0;
@@ -537,13 +539,14 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     int wn, wm;                          // (n, m) of the edge at hand (wave-uniform walk of the lower-triangular order)
     fcd_edge_to_pair(c0, wn, wm);
-    // slot words: four groups of 16 patients side by side per lane (ru_index): one 16-byte load per region and four groups
-    const int NQ = (NW16 + 3) >> 2;
-    const uint4 *__restrict__ ru = reinterpret_cast<const uint4 *>(r_U) + (int64_t)(w < GW ? w : 0) * Nreg * NQ * 64;
+    const uint32_t *__restrict__ ru = r_U + (int64_t)(w < GW ? w : 0) * Nreg * (NW16 <= 4 ? 4 : NW16) * 64;
     const uint32_t ul = (uint32_t)lane;
-    auto comp = [](const uint4 &v, int j) -> uint32_t { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
-    // slot words of the first four groups of the first edge: requested before the build so that their latency hides behind it
-    uint4 rn_q = ru[(uint32_t)((wn * NQ) * 64) + ul], rm_q = ru[(uint32_t)((wm * NQ) * 64) + ul];
+    // slot words of the first group of the first edge: requested before the build so that their latency hides behind it
+    // (slot word g of region n for this lane: [word][lane], or -- up to four words, forced onto this kernel by knob f_form = 2 --
+    // the four side by side of ru_index)
+    const uint32_t sn = NW16 <= 4 ? 256u : (uint32_t)NW16 * 64u, sg = NW16 <= 4 ? 1u : 64u, lo = NW16 <= 4 ? ul * 4u : ul;
+    auto ruw = [&](int n, int g) -> uint32_t { return ru[(uint32_t)n * sn + (uint32_t)g * sg + lo]; };      // (no branch around a load)
+    uint32_t rn_c = ruw(wn, 0), rm_c = ruw(wm, 0);
     float4 *edge_k = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ptile) + (size_t)EC * NPAIR * 128);   // [8]
     if (threadIdx.x < EC) edge_k[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -649,16 +652,11 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
         }
         const uint32_t tb = __builtin_amdgcn_readfirstlane(tile_off + (uint32_t)(e * NPAIR * 128));
         fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds
-        uint4 rn_n = rn_q, rm_n = rm_q;
         for (int g = 0; g < NG; ++g) {
-            // slot words of the next FOUR groups (of the next edge after the last): loaded at every fourth group, from a valid place
-            if ((g & 3) == 0) {
-                const bool last = (g >> 2) + 1 >= NQ;
-                const int pn = last ? nn : wn, pm = last ? nm : wm, pq = last ? 0 : (g >> 2) + 1;
-                rn_n = ru[(uint32_t)((pn * NQ + pq) * 64) + ul];
-                rm_n = ru[(uint32_t)((pm * NQ + pq) * 64) + ul];
-            }
-            const uint32_t rn_c = comp(rn_q, g & 3), rm_c = comp(rm_q, g & 3);
+            // slot words of the next group (of the next edge after the last group): always loaded, from a valid place
+            const bool last = g + 1 == NG;
+            const int pn = last ? nn : wn, pm = last ? nm : wm, pg = last ? 0 : g + 1;
+            const uint32_t rn_n = ruw(pn, pg), rm_n = ruw(pm, pg);
             const uint32_t zs = (rn_c ^ rm_c) | ((rn_c & rm_c) << 2);
             const uint32_t gb = tb + (uint32_t)(g * (8 * 128));
             if (NPAIR - 8 * g >= 8) {
@@ -681,10 +679,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
                     acc += *(lds_cf2v *)(uintptr_t)(off + gb + (uint32_t)(p * 128));
                 }
             }
-            if ((g & 3) == 3 || g + 1 == NG) {
-                rn_q = rn_n;
-                rm_q = rm_n;
-            }
+            rn_c = rn_n;
+            rm_c = rm_n;
         }
         acc += acc1;
         const float4 ek = edge_k[e];
@@ -699,7 +695,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
             const double *row = lMf + c * U * 6;
 #pragma unroll 1
             for (int g = 0; g < NG; ++g) {
-                const uint32_t a_ = comp(ru[(uint32_t)((wn * NQ + (g >> 2)) * 64) + ul], g & 3), b_ = comp(ru[(uint32_t)((wm * NQ + (g >> 2)) * 64) + ul], g & 3);
+                const uint32_t a_ = ruw(wn, g), b_ = ruw(wm, g);
                 fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), (a_ ^ b_) | ((a_ & b_) << 2), first, b1, b2);
             }
             b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
@@ -1168,8 +1164,9 @@ static f_plan f_plan_for(bool have_lMf, int64_t Nreg, int64_t U, int64_t GW, int
 
 size_t fcd_f_pass_ws_bytes(int64_t Nreg, int64_t U, int64_t GW) {
     // per-lane slot words r_U of the pair forms (the largest user; the other forms need nothing): 16 patients per word
-    // (four words side by side per lane: ru_index)
-    return (size_t)GW * Nreg * (((U + 15) / 16 + 3) / 4) * 64 * 4 * sizeof(uint32_t);
+    // (up to four words side by side per lane, else [word][lane]: ru_index)
+    const int64_t NW = (U + 15) / 16;
+    return (size_t)GW * Nreg * (NW <= 4 ? 4 : NW) * 64 * sizeof(uint32_t);
 }
 
 size_t fcd_fsq_need_bytes(int64_t Nreg, int64_t U, int64_t GW) {

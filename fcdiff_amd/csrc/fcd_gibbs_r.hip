@@ -1568,7 +1568,9 @@ int fcd_gibbs_r_step_sq(fcd_ctx *ctx, const double *lM, const double *lMd, const
         // four edges per wave and round)
         fcd_tally_f tf;
         tf.f_state = nullptr; tf.C = 0; tf.G = 0; tf.GW = 0; tf.acc = nullptr; tf.cnt_f = nullptr;
-        if (tally_f) {
+        // (only where the f state is small beside the packing's own work: at cfg5 -- 79 800 edges x 16 chain words -- the extra
+        // rows cost the launch 66 us for 16 us saved in the tally after the pass: profiles/r03_kernel_stats_cfg5.txt)
+        if (tally_f && g.C * g.GW <= 600000) {
             tf = *tally_f;
             const int64_t per_row = (int64_t)pgrid.x * pgrid.z;
             int64_t want = (g.C + 15) / 16;                       // workgroups of one round
