@@ -765,6 +765,45 @@ def test_gibbs_run_equals_call_by_call_loop(env, N, U, G, mode):
     nptest.assert_array_equal(again, out[1][5])
 
 
+def test_gibbs_f_pass_fp32_sums_repeat_path(env):
+    """
+    Round 4: the f pass accumulates its log-odds in fp32 and repeats an edge in fp64 when any lane's draw lies inside the
+    error-aware margin.  On WEAK data (two healthy subjects, broad components: the three types stay comparable)
+    the margin bites: the repeat path must run (counter f_repeats) and the chains must still be the oracle's, for the
+    U <= 64 kernel, the any-U kernel and with every draw forced down the exact path.
+    """
+    for (N, H, U, G, knob) in [(30, 2, 8, 256, {}), (30, 2, 8, 256, {"f_form": 2}), (12, 2, 70, 128, {}), (30, 2, 8, 256, {"f_tol": 1e30})]:
+        m = env.pkg.UnsharedRegionModel()
+        m.sigma = np.array([0.2, 0.25, 0.3])
+        m.mu = np.array([-0.05, 0.0, 0.05])
+        (_r, _t, _f, _ft, b, bt) = m.sample_fast(N, H, U, seed=N + U)
+        S_B, lM = env.CO.lik_tables(b, bt, m.theta())
+        ctx = env.ctx
+        for (k, v) in knob.items():
+            ctx.set_knob(k, v)
+        try:
+            eng = env.GibbsEngine(up(env, S_B), up(env, lM), N, U, G, seed=17, ctx=ctx)
+            eng.set_hyper(m.gamma, m.pi2())
+            eng.init(0.3)
+            rep0 = ctx.stat("f_repeats")
+            eng.sweeps(0, 3)
+            reps = ctx.stat("f_repeats") - rep0
+        finally:
+            for k in knob:
+                ctx.set_knob(k, 0)
+        f_o, r_o = env.CO.gibbs_init(G, N, U, 0.3, 17, 0)
+        for s_ in range(3):
+            env.CO.gibbs_f_step(f_o, r_o, S_B, lM, np.log(m.gamma), 17, s_, 0)
+            env.CO.gibbs_r_step(f_o, r_o, lM, np.log(m.pi2()), 17, s_, env.lib.EDGE_MODES["symmetric"], 0)
+        (f_g, r_g) = eng.export_state()
+        nptest.assert_array_equal(f_g, f_o)
+        nptest.assert_array_equal(r_g, r_o)
+        wave_edges = 3 * ((G + 63) // 64) * (N * (N - 1) // 2)
+        assert reps > 0, (N, U, knob)
+        if "f_tol" in knob:
+            assert reps == wave_edges                      # every (edge, chain word) went down the exact path
+
+
 def test_gibbs_chain_sharding_invariance(env):
     """A chain's path depends only on (seed, global chain id): 2 shards of 96 == one run of 192."""
     (N, U, G) = (12, 6, 192)
@@ -870,7 +909,9 @@ def test_gibbs_cfg3_size_properties(env):
         eng.init(0.05)
         eng.sweeps(0, 2)
         return eng
+    rep0 = env.ctx.stat("f_repeats")
     full = run(0, G)
+    f_repeats = env.ctx.stat("f_repeats") - rep0          # waves of the f pass that redid an edge's sums in fp64 (2 sweeps)
     n_alloc = env.ctx.stat("n_alloc")
     f_g, r_g = full.export_state()
     again = run(0, G).export_state()
@@ -897,7 +938,10 @@ def test_gibbs_cfg3_size_properties(env):
     margins = {"f_min_rel_distance_to_threshold": mf, "r_min_abs_v": mr, "r_fast_tolerance": 16 * 2e-5,
                "r_min_abs_v_over_fast_tolerance": mr / (16 * 2e-5), "r_sum_rounding_bound": 1e-11,
                "r_min_abs_v_over_rounding_bound": mr / 1e-11, "f_sum_rounding_bound": 1e-13,
-               "f_min_over_rounding_bound": mf / 1e-13, "draws_f": 2 * G * (N * (N - 1) // 2), "draws_r": 2 * G * N * U}
+               "f_min_over_rounding_bound": mf / 1e-13, "draws_f": 2 * G * (N * (N - 1) // 2), "draws_r": 2 * G * N * U,
+               # round 4: the f sums are fp32; a wave repeats an edge in fp64 when a lane's draw lies inside the error-aware margin
+               "f_wave_edges": 2 * (G // 64) * (N * (N - 1) // 2), "f_wave_edges_repeated_in_fp64": int(f_repeats),
+               "f_repeat_rate": float(f_repeats) / (2 * (G // 64) * (N * (N - 1) // 2))}
     print("tie margins (cfg3, 2 sweeps, 1024 chains):", margins)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
@@ -905,6 +949,7 @@ def test_gibbs_cfg3_size_properties(env):
         with open(os.path.join(out_dir, "tie_margin_cfg3.json"), "w") as fh:
             json.dump(margins, fh, indent=1)
     assert mr > 1e-9 and mf > 1e-11
+    assert margins["f_repeat_rate"] < 0.01               # (the floor of the margin alone is ~3e-4 per wave and edge)
     lj = full.logjoint().cpu().numpy()
     nptest.assert_allclose(lj[:8], env.CO.gibbs_logjoint(f_g[:8].copy(), r_g[:8].copy(), S_B, lM, lng, lnpi2), rtol=1e-12)
 
