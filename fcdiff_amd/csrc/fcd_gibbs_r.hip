@@ -412,7 +412,13 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int r
 
     // Blocks of 16 regions in groups of P_GRP: the state words of the NEXT group are requested before the
     // current group's terms run, so no global latency sits on the loop.
+#ifdef FCD_ABLATE
+    long long tr_wait = 0, tr_terms = 0, tr_issue = 0;           // (diagnostic build: where the loop's time goes, wave 0)
+#endif
     for (int bg = 0; bg < NBLK; bg += P_GRP) {
+#ifdef FCD_ABLATE
+        const long long tc0 = clock64();
+#endif
         // (always loaded, from a clamped block index: a guard around each load turns into a branch and a wait per word)
         uint2 fpn[P_GRP], rwn[P_GRP][UB];
 #pragma unroll
@@ -422,6 +428,17 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int r
 #pragma unroll
             for (int u = 0; u < UB; ++u) rwn[g][u] = rword(u, b);
         }
+#ifdef FCD_ABLATE
+        const long long tc1 = clock64();                          // the next group's loads are issued
+#pragma unroll
+        for (int g = 0; g < P_GRP; ++g) {
+            asm volatile("" ::"v"(fpv[g].x), "v"(fpv[g].y));
+#pragma unroll
+            for (int u = 0; u < UB; ++u) asm volatile("" ::"v"(rwv[g][u].x), "v"(rwv[g][u].y));
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GRP * (1 + UB)) : "memory");          // (this group's words have landed; the next group's stay in flight)
+        const long long tc2 = clock64();
+#endif
 #pragma unroll
         for (int g = 0; g < P_GRP; ++g) {
             const int b = bg + g;
@@ -432,9 +449,13 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int r
             for (int u = 0; u < UB; ++u) {
                 // one byte per pair: (q << 2) | tt, i.e. the offset of the term inside its pair record, / 8
                 const uint2 z = make_uint2(fpv[g].x | rwv[g][u].x, fpv[g].y | rwv[g][u].y);
+                // (the block's eight terms as a tree, one addition into the running sum: a chain of four dependent additions per
+                // block instead of eight -- the loop is bound by what ONE wave can have in flight, profiles/r04_trace_r_loop_cfg5.txt)
+                double t8[R_NB / 2];
 #pragma unroll
                 for (int p = 0; p < R_NB / 2; ++p)
-                    d[u] += *(lds_cdouble *)(uintptr_t)(pair_off(z, p) + base + (uint32_t)p * REC + (uint32_t)u * 288u);
+                    t8[p] = *(lds_cdouble *)(uintptr_t)(pair_off(z, p) + base + (uint32_t)p * REC + (uint32_t)u * 288u);
+                d[u] += ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
             }
         }
 #pragma unroll
@@ -443,10 +464,24 @@ __device__ __forceinline__ void r_role_panel(const r_step_args &a, int st, int r
 #pragma unroll
             for (int u = 0; u < UB; ++u) rwv[g][u] = rwn[g][u];
         }
+#ifdef FCD_ABLATE
+        {
+            asm volatile("" ::"v"(d[0]));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long tc3 = clock64();
+            tr_issue += tc1 - tc0;
+            tr_wait += tc2 - tc1;
+            tr_terms += tc3 - tc2;
+        }
+#endif
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u)
         if (u < nu) a.Pbuf[st & 1][(((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane] = (dpi + d[u]) - th[u];
+#ifdef FCD_ABLATE
+    FCD_TRACE_VAL(trec, 4, tr_wait);
+    FCD_TRACE_VAL(trec, 5, tr_terms | (tr_issue << 32));
+#endif
     FCD_TRACE(trec, 3);
 }
 
@@ -936,9 +971,15 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
                         const uint2 z = make_uint2(fpv[g].x | rwv[g][u].x, fpv[g].y | rwv[g][u].y);
+                        // (two trees of four per block -- see r_role_panel; a tree of eight costs this kernel eight registers it has not)
 #pragma unroll
-                        for (int p = 0; p < R_NB / 2; ++p)
-                            d[u] += *(lds_cdouble *)(uintptr_t)(pair_off6(z, p) + base + (uint32_t)p * REC + (uint32_t)u * 288u);
+                        for (int h = 0; h < 2; ++h) {
+                            double t4[4];
+#pragma unroll
+                            for (int p = 0; p < 4; ++p)
+                                t4[p] = *(lds_cdouble *)(uintptr_t)(pair_off6(z, 4 * h + p) + base + (uint32_t)(4 * h + p) * REC + (uint32_t)u * 288u);
+                            d[u] += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+                        }
                     }
                 }
 #pragma unroll
