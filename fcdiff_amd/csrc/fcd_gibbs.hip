@@ -636,6 +636,7 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pairx_kernel(const double *__
     }
     __syncthreads();
     if (w >= GW) return;
+    if (FCD_ABL(0, 3)) return;           // ablation: staging and build only
     const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
