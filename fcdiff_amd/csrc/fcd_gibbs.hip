@@ -298,6 +298,21 @@ __device__ __forceinline__ void fcd_f_exact_group(const double *__restrict__ row
     }
 }
 
+// The exact path of the U <= 64 kernel as ONE out-of-line function: inlined into the eight unrolled edge bodies it was most of
+// the kernel's text (fp64 exponentials, the gather loop), and the hot path had to be fetched around it.
+__device__ __attribute__((noinline)) int fcd_f_exact_edge(const double *__restrict__ row, double c1, double c2, uint32_t z0, uint32_t z1,
+                                                          uint32_t z2, uint32_t z3, int U, uint32_t xw) {
+    const int NPAIR = (U + 1) >> 1, NG = (NPAIR + 7) >> 3;
+    bool first = true;
+    double b1 = 0.0, b2 = 0.0;
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const uint32_t zs = g == 0 ? z0 : g == 1 ? z1 : g == 2 ? z2 : z3;
+        fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), zs, first, b1, b2);
+    }
+    return fcd_draw_f(0.0, c1 + b1, c2 + b2, fcd_u32(xw));
+}
+
 template <int NW16>
 __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__restrict__ S_B, const double *__restrict__ lMf,
                                                             const double *__restrict__ hyper, uint8_t *__restrict__ f_state,
@@ -481,15 +496,8 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             int k = fcd_draw_f_fast32(ek.x + acc.x, ek.y + acc.y, (float)xw * 2.3283064e-10f, ek.z, margin, &amb);
             if (__ballot(amb) != 0ull) {
                 // somewhere in the wave the fp32 sums cannot decide the draw: the edge again, in fp64, for the whole wave
-                bool first = true;
-                double b1 = 0.0, b2 = 0.0;
-                const double *row = lMf + c * U * 6;
-#pragma unroll
-                for (int g = 0; g < NW16; ++g)
-                    if (g < NG) fcd_f_exact_group(row, U, 16 * g, min(8, NPAIR - 8 * g), Zc[g], first, b1, b2);
-                b1 = lg1 + ((S_B[c * 3 + 1] - S_B[c * 3 + 0]) + b1);
-                b2 = lg2 + ((S_B[c * 3 + 2] - S_B[c * 3 + 0]) + b2);
-                k = fcd_draw_f(0.0, b1, b2, fcd_u32(xw));
+                k = fcd_f_exact_edge(lMf + c * U * 6, lg1 + (S_B[c * 3 + 1] - S_B[c * 3 + 0]), lg2 + (S_B[c * 3 + 2] - S_B[c * 3 + 0]), Zc[0],
+                                     NW16 > 1 ? Zc[NW16 > 1 ? 1 : 0] : 0u, NW16 > 2 ? Zc[NW16 > 2 ? 2 : 0] : 0u, NW16 > 3 ? Zc[NW16 > 3 ? 3 : 0] : 0u, U, xw);
                 if (lane == 0) atomicAdd(dbg, 1ull);
             }
             (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
