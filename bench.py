@@ -412,8 +412,13 @@ def main():
                                "sample": "%d chains x %d sweeps of the same %s tables with the C restatement "
                                          "(oracle/fcdiff_oracle.c, OpenMP over chains), %.1f s" % (n_c, n_sw, cfg_key, t_c)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_pg:
+        torch.cuda.synchronize()
+        try:
+            ctx.detach_comm()            # the library's own communicator first (nothing of it is in flight any more)
+        except Exception:
+            pass
         dist.destroy_process_group()
 
 

@@ -262,8 +262,29 @@ def run_chains(engine, n_sweeps, sweep0=0, mstep_every=1, burn_in=0, update_thet
         # Round 4: the all-reduce of the pooled counts is RCCL called by the library itself on the stream of the sweep
         # kernels (fcd_comm_*): the several-rank loop is then the one-rank loop -- ONE fcd_gibbs_run call per chunk, the
         # tally, the all-reduce, the M-step kernel and the next f pass queued behind one another.
-        engine.ctx.attach_comm(group)
-        collective = False
+        # (the path has only ever run on ONE rank -- the build box has one GPU -- so it is taken only if EVERY rank could make
+        # its communicator: one all-reduce of a flag through the torch group decides, all ranks alike; else round 3's loop)
+        import torch
+        decided = getattr(engine, "_direct_comm", None)            # (the agreement is made once per engine, not once per call)
+        if decided is not None:
+            collective = not decided
+        ok = 1
+        try:
+            if decided is None:
+                engine.ctx.attach_comm(group)
+        except Exception as exc:      # noqa: BLE001
+            import warnings
+            warnings.warn("fcdiff_amd: the library's own RCCL communicator could not be made (%s); pooling the counts through "
+                          "torch.distributed instead" % (exc,))
+            ok = 0
+        if decided is None:
+            flag = torch.tensor([ok], dtype=torch.int32, device=engine.ctx.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            engine._direct_comm = int(flag.item()) == 1
+            if engine._direct_comm:
+                collective = False
+            else:
+                engine.ctx.detach_comm()
     if not collective and on_sweep is None and not mstep_lag:
         engine.run(sweep0, n_sweeps, mstep_every=k, accumulate_from=acc_from)
         return

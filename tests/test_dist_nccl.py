@@ -16,7 +16,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir, with_group=True, force=False, direct=True):
+def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir, with_group=True, force=False, direct=True,
+            break_direct=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,6 +40,10 @@ def _worker(rank, world, port, total, n_sweeps, seed, mstep_every, lag, out_dir,
         fit._update_lps()
         (chain0, n_local) = shard_chains(total, world, rank)
         eng = GibbsEngine(fit._d["S_B"], fit._d["lM"], N, U, n_local, chain0=chain0, seed=seed, ctx=fit._context())
+        if break_direct:                  # the library's communicator "cannot be made": run_chains must fall back to torch, on every rank alike
+            def _fail(group=None):
+                raise RuntimeError("simulated RCCL failure")
+            eng.ctx.attach_comm = _fail
         eng.set_hyper(m.gamma, m.pi2())
         eng.init(0.2)
         run_chains(eng, n_sweeps, mstep_every=mstep_every, burn_in=1, mstep_lag=lag, force_collective=force, direct=direct)
@@ -87,7 +92,7 @@ def test_two_gpus_equal_one_process(tmp_path, mstep_every, lag, direct):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mstep_every,lag,direct", [(1, 0, True), (2, 0, True), (1, 0, False), (1, 1, False), (2, 1, False)])
+@pytest.mark.parametrize("mstep_every,lag,direct", [(1, 0, True), (2, 0, True), (1, 0, False), (1, 1, False), (2, 1, False), (1, 0, "broken")])
 def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag, direct):
     """
     RCCL on the one GPU of the build box: a process group of ONE rank (backend nccl, initialised before anything touches
@@ -109,7 +114,10 @@ def test_one_gpu_process_group_of_one_rank(tmp_path, mstep_every, lag, direct):
     plain.mkdir()
     group.mkdir()
     mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(plain), False, False), nprocs=1, join=True)
-    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(group), True, True, direct), nprocs=1, join=True)
+    broken = direct == "broken"          # (direct asked for, the communicator "fails": the loop through torch.distributed must take over)
+    mp.spawn(_worker, args=(1, _free_port(), total, n_sweeps, seed, mstep_every, lag, str(group), True, True, bool(direct), broken), nprocs=1,
+             join=True)
+    direct = bool(direct) and not broken
     a = np.load(os.path.join(str(plain), "rank0.npz"))
     b = np.load(os.path.join(str(group), "rank0.npz"))
     assert int(b["world"]) == 1 and int(b["r_form"]) == 2          # (the pipelined form ran beside the collective)
