@@ -330,6 +330,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
     const double lg2 = hyper[FCD_H_LNGAMMA + 2] - hyper[FCD_H_LNGAMMA + 0];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    [[maybe_unused]] const int trec = (int)blockIdx.x < 4096 ? (int)blockIdx.x : 4095;      // (diagnostic build: profiles/trace_f.py)
+    FCD_TRACE(trec, 0);
+    FCD_TRACE_VAL(trec, 7, (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff));
     // the r words of the tile's edges: loaded before the barrier so their latency hides behind the staging.
     // Consecutive edges c = n(n-1)/2 + m share n: its words are fetched once per run, not once per edge.
     // Slot numbers (x_u, x_u+1, a_u, a_u+1) of 8 pairs of patients per word, for the edge at hand only: the words of
@@ -351,6 +354,12 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
             Zc[j] = (rn[j] ^ rm) | ((rn[j] & rm) << 2);
         }
     }
+    // S_B of the tile's edges (lane l < 3 of wave e: S_B[c0 + e][l]): asked for HERE, beside the rows -- the build phase turns them
+    // into the edge's constants, and a trip to memory in the middle of that phase sat on every tile's critical path
+    // (profiles/r04_trace_f.txt: built 3.8 us of a 17 us tile)
+    const int wv0 = (int)(threadIdx.x >> 6);
+    double sbv = 0.0;
+    if (wv0 < ne && lane < 3) sbv = S_B[(c0 + wv0) * 3 + lane];
     {
         // the tile's rows of lMf are one contiguous piece: coalesced 16-byte copies
         const int n_d2 = ne * U * 3;
@@ -364,39 +373,43 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
         }
     }
     __syncthreads();
+    FCD_TRACE(trec, 1);
     {
-        // pair records from the single rows in LDS: a thread keeps its slot (blockDim is a multiple of 16).  The records are
-        // fp32 (one rounding of the fp64 sum of the two rows): half the LDS, and a term is one 8-byte read and ONE packed add.
-        fcd_f2v *dst = reinterpret_cast<fcd_f2v *>(ptile);
-        const int slot = threadIdx.x & 15;
-        const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
-        const bool valid = !((x0 & a0) | (x1 & a1));
-        const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
+        // pair records from the single rows in LDS, ONE THREAD PER (edge, pair): six 16-byte reads (the three mixture cases of
+        // patient u and of patient u+1), the nine valid sums, rounded once to fp32, eight 16-byte writes (two slots each; the
+        // seven impossible slots -- x and a both set for a patient -- as zeros).  Round 3's build gave every (pair, slot) entry a
+        // thread of its own: 16 x the index arithmetic and 7/16 of the threads making zeros -- 3.7 us of a 17 us tile
+        // (profiles/r04_trace_f.txt).
+        typedef float fcd_f4v __attribute__((ext_vector_type(4)));
+        fcd_f4v *dst4 = reinterpret_cast<fcd_f4v *>(ptile);
         const int total = ne * NPAIR;
-        // (edge, pair) of record ep, stepped without an integer division per turn
-        const int stride = blockDim.x >> 4;
-        const int sq_ = stride / NPAIR, sr_ = stride - sq_ * NPAIR;
-        int e = (int)(threadIdx.x >> 4) / NPAIR, pr = (int)(threadIdx.x >> 4) - e * NPAIR;
-        for (int ep = threadIdx.x >> 4; ep < total; ep += stride, e += sq_, pr += sr_) {
-            if (pr >= NPAIR) {
-                pr -= NPAIR;
-                ++e;
-            }
+        // (the records are made by the UPPER half of the workgroup's waves: the lower ones make the edges' bounds below)
+        const int half = (int)(blockDim.x >> 7) << 6;
+        const int tb = (int)threadIdx.x >= half ? (int)threadIdx.x - half : (int)threadIdx.x + ((int)blockDim.x - half);
+        for (int ep = tb; ep < total; ep += blockDim.x) {
+            const int e = ep / NPAIR, pr = ep - e * NPAIR;
             const int u = 2 * pr;
-            double2 v = make_double2(0.0, 0.0);
-            if (valid) {
-                const double2 *su = single + (e * U + u) * 3;
-                v = su[l0];
-                if (u + 1 < U) {
-                    const double2 v1 = su[3 + l1];
-                    v.x += v1.x;
-                    v.y += v1.y;
-                }
+            const double2 *su = single + (e * U + u) * 3;
+            double2 A[3], B[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                A[l] = su[l];
+                B[l] = (u + 1 < U) ? su[3 + l] : make_double2(0.0, 0.0);
             }
-            fcd_f2v o;
-            o.x = (float)v.x;
-            o.y = (float)v.y;
-            dst[(pr * FP_EC + e) * 16 + slot] = o;       // [pair][edge][slot]: see the reads below
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                fcd_f4v o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int slot = 2 * s2 + h;
+                    const int x0 = slot & 1, x1 = (slot >> 1) & 1, a0 = (slot >> 2) & 1, a1 = slot >> 3;
+                    const bool valid = !((x0 & a0) | (x1 & a1));
+                    const int l0 = a0 ? 1 : (x0 ? 2 : 0), l1 = a1 ? 1 : (x1 ? 2 : 0);          // 0 typical, 1 both, 2 discordant
+                    const float vx = valid ? (float)(A[l0].x + B[l1].x) : 0.f, vy = valid ? (float)(A[l0].y + B[l1].y) : 0.f;
+                    if (h == 0) { o.x = vx; o.y = vy; } else { o.z = vx; o.w = vy; }
+                }
+                dst4[(pr * FP_EC + e) * 8 + s2] = o;       // [pair][edge][slot]: see the reads below
+            }
         }
         // B_e >= sum over the pairs of max |record entry|: the sum over the patients of the largest |value| of the row
         // (wave e does edge e, lane = patient; U <= 64) -- what bounds the error of the fp32 sums below
@@ -414,15 +427,30 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 // the edge's constants as the draw wants them: the two log-odds offsets in fp32 and the relative uncertainty
                 // of the weights that the error bound of the whole fp32 sum (NPAIR records, then the offset) amounts to
                 const int64_t c = c0 + ee;
-                const double c1 = lg1 + (S_B[c * 3 + 1] - S_B[c * 3 + 0]), c2 = lg2 + (S_B[c * 3 + 2] - S_B[c * 3 + 0]);
+                double sb0, sb1, sb2;
+                if (ee == wv0) {                       // (this wave's own edge: the values asked for at the top)
+                    const uint64_t bits = (uint64_t)__double_as_longlong(sbv);      // lane 0 holds S_B[c][0]; lanes 1, 2 the others
+                    auto lane_val = [&](int l) -> double {
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), l);
+                        return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+                    };
+                    sb0 = lane_val(0); sb1 = lane_val(1); sb2 = lane_val(2);
+                } else {
+                    sb0 = S_B[c * 3 + 0]; sb1 = S_B[c * 3 + 1]; sb2 = S_B[c * 3 + 2];
+                }
+                const double c1 = lg1 + (sb1 - sb0), c2 = lg2 + (sb2 - sb0);
                 const float cm = fmaxf((float)fabs(c1), (float)fabs(c2)) * 1.0000002f;
                 edge_k[ee] = make_float4((float)c1, (float)c2, fcd_draw_f_eta(fcd_f32_sum_err(NPAIR, a) + fcd_f32_offset_err(cm, a)), 0.f);
             }
         }
     }
     __syncthreads();
+    FCD_TRACE(trec, 2);
     if (w >= GW) return;
     if (FCD_ABL(0, 3)) return;           // ablation: staging only
+#ifdef FCD_ABLATE
+    long long tr_terms = 0, tr_draw = 0, tr_rest = 0;
+#endif
     const uint32_t chain = chain0 + (uint32_t)w * 64u + lane;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     fcd_u4 rnd = {0, 0, 0, 0};
@@ -448,6 +476,9 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 vmn = ru[(uint32_t)(nm * 64) + ul];
                 if (new_row) vnn = ru[(uint32_t)(nn * 64) + ul];
             }
+#ifdef FCD_ABLATE
+            const long long tc0 = clock64();
+#endif
             fcd_f2v acc = {0.f, 0.f}, acc1 = {0.f, 0.f};    // even / odd pairs: two chains of packed adds, none waits for the one before
 #pragma unroll
             for (int g = 0; g < NW16; ++g) {
@@ -485,6 +516,10 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 }
             }
             acc += acc1;
+#ifdef FCD_ABLATE
+            asm volatile("" ::"v"(acc.x), "v"(acc.y));
+            const long long tc1 = clock64();
+#endif
             const float4 ek = edge_k[e];
             if (FCD_ABL(0, 2)) {             // ablation: no RNG / exp
                 f_state[((int64_t)w * C + c) * 64 + lane] = (uint8_t)(acc.x > acc.y ? 1 : 2);
@@ -500,6 +535,10 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                                      NW16 > 1 ? Zc[NW16 > 1 ? 1 : 0] : 0u, NW16 > 2 ? Zc[NW16 > 2 ? 2 : 0] : 0u, NW16 > 3 ? Zc[NW16 > 3 ? 3 : 0] : 0u, U, xw);
                 if (lane == 0) atomicAdd(dbg, 1ull);
             }
+#ifdef FCD_ABLATE
+            asm volatile("" ::"v"(k));
+            const long long tc2 = clock64();
+#endif
             (f_state + ((int64_t)w * C + c) * 64)[(uint32_t)lane] = (uint8_t)k;     // (scalar base + lane)
             if (fsq) {
                 // square copy for the r pass that follows (fcd_gibbs_sweeps): rows of it are contiguous in m
@@ -517,8 +556,23 @@ __global__ __launch_bounds__(1024, 8) void gibbs_f_pair_kernel(const double *__r
                 wn = nn;
                 wm = nm;
             }
+#ifdef FCD_ABLATE
+            {
+                asm volatile("" ::"v"(Zc[0]));
+                const long long tc3 = clock64();
+                tr_terms += tc1 - tc0;
+                tr_draw += tc2 - tc1;
+                tr_rest += tc3 - tc2;
+            }
+#endif
         }
     }
+#ifdef FCD_ABLATE
+    FCD_TRACE_VAL(trec, 4, tr_terms);
+    FCD_TRACE_VAL(trec, 5, tr_draw);
+    FCD_TRACE_VAL(trec, 6, tr_rest);
+#endif
+    FCD_TRACE(trec, 3);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -45,6 +45,11 @@ BODY(k_cmp64, "v_cmp_lt_f64 vcc, %4, %5\n v_cmp_lt_f64 vcc, %5, %4")
 BODY(k_exp, "v_exp_f32 %0, %0\n v_exp_f32 %2, %2")
 BODY(k_cvt, "v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %2, %5")
 BODY(k_fmac32, "v_fmac_f32_e32 %0, 1.0, %1\n v_fmac_f32_e32 %2, 1.0, %3")
+// 64-bit product of two 32-bit words in ONE instruction (what the compiler makes of Philox's mulhilo): the pair %4 (x) / %5 (y) as 64-bit destinations
+BODY(k_mad64, "v_mad_u64_u32 %4, vcc, %0, %1, 0\n v_mad_u64_u32 %5, vcc, %2, %3, 0")
+BODY(k_exp_log, "v_log_f32 %0, %0\n v_log_f32 %2, %2")
+BODY(k_max3, "v_max3_f32 %0, %1, %0, %3\n v_max3_f32 %2, %3, %2, %1")
+BODY(k_cvtu, "v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %2, %2")
 
 int main() {
     hipDeviceProp_t p;
@@ -56,7 +61,8 @@ int main() {
         {"v_and_b32", k_and}, {"v_lshrrev_b32", k_lshr}, {"v_and_or_b32 (inline const)", k_andor}, {"v_and_b32 (literal)", k_andlit},
         {"v_add_u32", k_addu}, {"v_lshl_add_u32", k_lshladd}, {"v_bfe_u32", k_bfe}, {"v_mad_u32_u24", k_madu24}, {"v_perm_b32", k_perm},
         {"v_fma_f32", k_fma32}, {"v_add_f64", k_add64}, {"v_mul_hi_u32", k_mulhi}, {"v_mul_lo_u32", k_mullo}, {"v_cndmask_b32", k_cndmask},
-        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}, {"v_fmac_f64_e32 (VOP2, x 1.0)", k_fmac64}, {"v_fma_f64 (VOP3)", k_fma64}, {"v_fmac_f32_e32", k_fmac32}, {"v_cndmask_b32_e64 (SGPR-pair mask)", k_cndmask_s}, {"v_cndmask_b32_e64 (constants, SGPR mask)", k_cndmask_c}, {"v_addc_co_u32 (vcc in/out)", k_addc}, {"v_cmp_lt_f32 -> vcc", k_cmp}, {"v_cmp_lt_f64 -> vcc", k_cmp64}, {"v_exp_f32", k_exp}, {"v_cvt_f32_f64", k_cvt}};
+        {"v_or_b32_sdwa (byte select)", k_sdwa}, {"v_pk_add_f32", k_pkadd}, {"v_fmac_f64_e32 (VOP2, x 1.0)", k_fmac64}, {"v_fma_f64 (VOP3)", k_fma64}, {"v_fmac_f32_e32", k_fmac32}, {"v_cndmask_b32_e64 (SGPR-pair mask)", k_cndmask_s}, {"v_cndmask_b32_e64 (constants, SGPR mask)", k_cndmask_c}, {"v_addc_co_u32 (vcc in/out)", k_addc}, {"v_cmp_lt_f32 -> vcc", k_cmp}, {"v_cmp_lt_f64 -> vcc", k_cmp64}, {"v_exp_f32", k_exp}, {"v_cvt_f32_f64", k_cvt},
+        {"v_mad_u64_u32 (64-bit product)", k_mad64}, {"v_log_f32", k_exp_log}, {"v_max3_f32", k_max3}, {"v_cvt_f32_u32", k_cvtu}};
     const int iters = 2000;
     uint64_t *h = (uint64_t *)malloc((size_t)cus * 4 * 8 * 8);
     for (auto &k : ks) {
