@@ -260,6 +260,17 @@ __device__ static inline int fcd_draw_f_fast32(float bf1, float bf2, float xf, f
     *amb = !(fabsf(t - e0) >= m && fabsf(t - (e0 + e1)) >= m);
     return (t < e0) ? 0 : ((t < e0 + e1) ? 1 : 2);
 }
+// The draw without an exponential, where it is certain: if the largest of (0, b1, b2) leads the second by more than 15 + eta
+// (eta >= twice the sums' error bound), the two other weights together are below 2 e^-15 = 6.1e-7 of the largest, and any x in
+// [1e-6, 1 - 1e-6] falls into the largest one's interval of the inverse CDF whatever the order of the three: k = argmax,
+// exactly what fcd_draw_f returns.  Returns false where that cannot be said (the caller then takes fcd_draw_f_fast32).
+// On well separated data nearly every draw is of this kind; on weak data the test costs a dozen instructions.
+__device__ static inline bool fcd_draw_f_sure(float bf1, float bf2, float xf, float eta, int *k) {
+    const float mx = fmaxf(0.f, fmaxf(bf1, bf2)), mn = fminf(0.f, fminf(bf1, bf2));
+    const float mid = ((bf1 + bf2) - mx) - mn;                        // (the middle one of 0, b1, b2, to within rounding: covered by the 1e-2)
+    *k = (bf2 >= mx) ? 2 : ((bf1 >= mx) ? 1 : 0);
+    return (mx - mid) - eta > 15.01f && xf > 1e-6f && xf < 0.999999f;
+}
 // absolute error bound of an fp32 sum of n terms, each first rounded to fp32, given B >= sum of |terms|: the n conversions
 // cost at most 2^-24 B together, each of the n - 1 additions at most 2^-24 times a partial sum of magnitude <= B
 __host__ __device__ static inline float fcd_f32_sum_err(int n_terms, float B) { return (float)(n_terms + 1) * 5.97e-8f * 1.01f * B; }
