@@ -163,6 +163,7 @@ int fcd_ctx_create(fcd_ctx **out) {
     ctx->knobs.r_nopad = (int)knob_env("FCD_R_NOPAD");
     ctx->knobs.r_dsplit = (int)knob_env("FCD_R_DSPLIT");
     ctx->knobs.r_coop = (int)knob_env("FCD_R_COOP");
+    ctx->knobs.qr_form = (int)knob_env("FCD_QR_FORM");
     ctx->knobs.r_refill = (int)knob_env("FCD_R_REFILL");
     ctx->knobs.r_tol = knob_env("FCD_R_TOL");
     ctx->knobs.f_tol = knob_env("FCD_F_TOL");
@@ -249,6 +250,7 @@ int fcd_ctx_set_knob(fcd_ctx *ctx, const char *name, double value) {
     else if (!strcmp(name, "r_nopad")) k.r_nopad = (int)value;
     else if (!strcmp(name, "r_dsplit")) k.r_dsplit = (int)value;
     else if (!strcmp(name, "r_coop")) k.r_coop = (int)value;
+    else if (!strcmp(name, "qr_form")) k.qr_form = (int)value;
     else if (!strcmp(name, "r_refill")) k.r_refill = (int)value;
     else if (!strcmp(name, "r_tol")) k.r_tol = value;
     else if (!strcmp(name, "f_tol")) k.f_tol = value;

@@ -22,6 +22,8 @@ struct fcd_knobs {
     int r_ub;          // patients per panel workgroup of the blocked r pass: 0 = automatic, else 1 / 2 / 4
     int r_nopad;       // 1: no empty workgroups beside the in-order workgroups
     int r_refill;      // 1: the packing launch writes the panel-value sentinels in every sweep (default: only in the first sweep of a fcd_gibbs_run call)
+    int qr_form;       // variational q_R update: 0 = by size; 1 = gathers from the edge-major table inside the region loop (rounds 1-3);
+                       // 2 = region-major weights made first, whatever their size
     int r_coop;        // pipelined r pass: 1 = cooperative launch (the runtime checks that the grid is co-resident; +16 us per pass), else plain
     int r_dsplit;      // 1: ONE in-order workgroup per patient in the pipelined r pass (default: two, 8 chain words each, where there are more than 8)
     double r_tol;      // > default: widen the margin inside which an r draw is re-decided with the exact logit

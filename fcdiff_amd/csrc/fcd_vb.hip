@@ -3,6 +3,7 @@
 //
 // All four read lM (C,U,3,3) once per call: HBM/L2-bound, algorithmic bytes 72*C*U + small.
 #include "fcd_common.h"
+#include "fcd_fastmath.h"
 
 namespace {
 
@@ -72,12 +73,214 @@ __global__ __launch_bounds__(256) void vb_expF_kernel(const double *__restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) qF[i] = exp(lq_F[i]);
 }
 
-// One block per patient (patients are independent), regions strictly in order (Gauss-Seidel, fit.py:184-197), the
-// threads split the sum over m.  The operands of region n+1 (its 9 table values and 3 q_F per thread and m) do not
+// q_R update, fit.py:176-198.  Two launches:
+//  (1) vb_qR_weights_kernel -- everything of a term that does not depend on q_R, for every ordered pair of regions at once:
+//        W[u][n][m][x] = sum_k q_F[c, k] * lM[c, u, k, x],   c = the edge id fit.py:186 uses for (n, m) (quirk Q1), x = 0, 1, 2
+//      one thread per (u, n, m): the scattered 72-byte reads of the edge-major table happen HERE, fully parallel, and W is
+//      region-major (rows contiguous in m).
+//  (2) vb_qR_kernel -- one block per patient (patients are independent), regions strictly in order (Gauss-Seidel,
+//      fit.py:184-197), the threads split the sum over m:
+//        s0 = ln(1-pi) + sum_m (q0m W0 + q1m W2),   s1 = ln pi + sum_m (q1m W1 + q0m W2)         fit.py:188-194
+//      reading ONE coalesced row of W per region (round 3 gathered 12 doubles per thread and region from the edge-major
+//      table inside the serial loop: ~500 cache lines per region and block through one CU's address unit, 1.5 us per
+//      region whatever else the loop did).  The rows of the next NB - 1 regions are in flight while a region is reduced.
+//      The serial chain of a region: wave sums, one barrier, logsumexp and two exponentials in every thread -- on the
+//      table-driven exp / log of fcd_fastmath.h (K_lik's: <= 1.5 ulp, ~20 instructions each; ocml's take ~35 / ~70), in
+//      the SAME order of operations as scipy's logsumexp (max, exp of the differences, log of the sum, + max); arguments
+//      the tables do not cover (sum not in [1, 2], exponent below -700) take ocml's functions.
+// (The sum over k is taken before the sum over m here; the reference nests them the other way round: rounding differs
+//  by a few ulp of a term, inside the tolerance every summed quantity has, tests/test_gpu_parity.py.)
+struct QrTabs {
+    double exp_tab[FCD_EXP_CELLS];
+    fcd_log_cell log_tab[FCD_LOG_CELLS];
+};
+// grid (chunks of QW_M regions m, Nreg rows n, chunks of 64 patients), one wave per block: lane = patient, so the nine table
+// values of (edge, patient) are read the way the table lies (72-byte records side by side over the patients), the edge id and
+// the three q_F are wave-uniform (scalar loads), and a lane writes QW_M x 24 contiguous bytes of its patient's row.
+constexpr int QW_M = 16;
+__global__ __launch_bounds__(64) void vb_qR_weights_kernel(const double *__restrict__ qF, const double *__restrict__ lM, int Nreg,
+                                                           int U, int mode, double *__restrict__ W) {
+    const int n = blockIdx.y, m0 = blockIdx.x * QW_M;
+    const int u = blockIdx.z * 64 + (int)threadIdx.x;
+    const int uc = u < U ? u : U - 1;
+    double *__restrict__ out = W + (((int64_t)uc * Nreg + n) * Nreg + m0) * 3;
+#pragma unroll 4
+    for (int mi = 0; mi < QW_M; ++mi) {
+        const int m = m0 + mi;
+        if (m >= Nreg) break;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        if (m != n) {
+            const int64_t c = fcd_pair_to_edge(n, m, mode);
+            const double *p = lM + (c * U + uc) * 9;
+            const double f0 = qF[c * 3 + 0], f1 = qF[c * 3 + 1], f2 = qF[c * 3 + 2];
+            w0 = (f0 * p[0] + f1 * p[3]) + f2 * p[6];
+            w1 = (f0 * p[1] + f1 * p[4]) + f2 * p[7];
+            w2 = (f0 * p[2] + f1 * p[5]) + f2 * p[8];
+        }
+        if (u < U) {
+            out[mi * 3 + 0] = w0;
+            out[mi * 3 + 1] = w1;
+            out[mi * 3 + 2] = w2;
+        }
+    }
+}
+
+// sum over the 64 lanes of a wave, the same value returned to every lane: DPP moves inside the rows of 16 lanes, two row
+// broadcasts, one v_readlane -- ~20 instructions, no LDS (six __shfl_xor of a double are twelve ds_bpermute round trips:
+// most of a region's serial chain in round 3's kernel)
+__device__ inline double qr_dpp_get(double v, const int ctrl, const int row_mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl == 0xB1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
+    else if (ctrl == 0x4E) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
+    else if (ctrl == 0x141) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); }
+    else if (ctrl == 0x140) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); }
+    else if (ctrl == 0x142) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); }
+    else { lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false); }
+    (void)row_mask;
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double qr_wave_sum(double v) {
+    v += qr_dpp_get(v, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+    v += qr_dpp_get(v, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+    v += qr_dpp_get(v, 0x141, 0xF);     // row_half_mirror
+    v += qr_dpp_get(v, 0x140, 0xF);     // row_mirror: every lane of a row holds the row's sum
+    v += qr_dpp_get(v, 0x142, 0xA);     // row_bcast:15 into rows 1 and 3
+    v += qr_dpp_get(v, 0x143, 0xC);     // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// WAVES = 1: one wave per patient, nothing crosses waves (no LDS partials, no barrier); WAVES = 4: Nreg > 512.
+template <int WAVES, int MPT, int NB>   // regions m per thread: Nreg <= MPT * 64 * WAVES; NB row buffers
+__global__ __launch_bounds__(64 * WAVES) void vb_qR_kernel(const double *__restrict__ W, const double *__restrict__ hyper,
+                                                           const QrTabs *__restrict__ tabs, int Nreg, int U,
+                                                           double *__restrict__ lq_R) {
+    constexpr int BLOCK = 64 * WAVES;
+    __shared__ double red[2][2 * WAVES];                // wave partials, double-buffered: one barrier per region
+    __shared__ double etab[FCD_EXP_CELLS];
+    __shared__ fcd_log_cell ltab[FCD_LOG_CELLS];
+    const int u = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < FCD_LOG_CELLS; t += BLOCK) ltab[t] = tabs->log_tab[t];
+    if (tid < FCD_EXP_CELLS) etab[tid] = tabs->exp_tab[tid];
+    // q of the thread's own regions m = tid + j * BLOCK lives in registers; every thread finishes every region
+    // itself (same arithmetic in all lanes), so nothing but the wave partials crosses threads
+    double q0m[MPT], q1m[MPT];
+#pragma unroll
+    for (int j = 0; j < MPT; ++j) {
+        const int m = tid + j * BLOCK;
+        q0m[j] = m < Nreg ? exp(lq_R[((int64_t)m * U + u) * 2 + 0]) : 0.0;
+        q1m[j] = m < Nreg ? exp(lq_R[((int64_t)m * U + u) * 2 + 1]) : 0.0;
+    }
+    struct Op {
+        double w[3];
+    };
+    const double *__restrict__ Wu = W + (int64_t)u * Nreg * Nreg * 3;
+    auto load = [&](int n, Op (&o)[MPT]) {
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            const int m = tid + j * BLOCK;
+            const double *p = Wu + ((int64_t)n * Nreg + (m < Nreg ? m : 0)) * 3;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) o[j].w[x] = m < Nreg ? p[x] : 0.0;      // (W[u][n][n] is zero)
+        }
+    };
+    Op buf[NB][MPT];
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+        if (b < Nreg) load(b, buf[b]);
+    __syncthreads();                                     // the tables are in place
+    const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
+    // exp(d), d <= 0 (or NaN)
+    auto exp_le0 = [&](double d) -> double {
+        const double y = -d;
+        if (__builtin_expect(!(y <= 700.0), 0)) return exp(d);       // (block-uniform: every thread holds the same d)
+        return fcd_exp_neg(y, etab);
+    };
+    auto step = [&](int n, Op (&cur)[MPT], Op (&fill)[MPT]) {
+        if (n + NB - 1 < Nreg) load(n + NB - 1, fill);
+        double t0 = 0.0, t1 = 0.0;
+        double a0[MPT], a1[MPT];
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            const double qm0 = q0m[j], qm1 = q1m[j];
+            a0[j] = qm0 * cur[j].w[0] + qm1 * cur[j].w[2];       // fit.py:188-190
+            a1[j] = qm1 * cur[j].w[1] + qm0 * cur[j].w[2];       // fit.py:192-194
+        }
+#pragma unroll
+        for (int st = 1; st < MPT; st *= 2) {                    // (a tree: the depth of the chain, not the number of additions)
+#pragma unroll
+            for (int j = 0; j + st < MPT; j += 2 * st) {
+                a0[j] += a0[j + st];
+                a1[j] += a1[j + st];
+            }
+        }
+        t0 = a0[0];
+        t1 = a1[0];
+        t0 = qr_wave_sum(t0);
+        t1 = qr_wave_sum(t1);
+        double s0 = lnpi0, s1 = lnpi1;
+        if (WAVES == 1) {
+            s0 += t0;
+            s1 += t1;
+        } else {
+            double *rb = red[n & 1];
+            if ((tid & 63) == 0) {
+                rb[(tid >> 6) * 2 + 0] = t0;
+                rb[(tid >> 6) * 2 + 1] = t1;
+            }
+            __syncthreads();
+            for (int w = 0; w < WAVES; ++w) {
+                s0 += rb[w * 2 + 0];
+                s1 += rb[w * 2 + 1];
+            }
+        }
+        // z = logsumexp(s0, s1); lq = s - z; q = exp(lq)                  fit.py:196-197
+        // logsumexp in scipy's order of operations (max, exp of the differences, log of their sum, + max).  The NEXT region
+        // waits for q only, and q = exp(s - z) = exp(s - max) / sum: taken from the two exponentials the sum is made of
+        // (one division) instead of a third and fourth exponential behind the logarithm -- the logarithm and the stores
+        // of lq leave the serial chain (q differs from exp(lq) by an ulp or two: inside the tolerance of everything summed).
+        double mx = fmax(s0, s1);
+        if (!isfinite(mx)) mx = 0.0;
+        const double d0 = s0 - mx, d1 = s1 - mx;
+        double e0, e1;
+        if (__builtin_expect(d0 <= 0.0 && d1 <= 0.0 && (d0 == 0.0 || d1 == 0.0), 1)) {
+            const double x0 = d0 == 0.0 ? 1.0 : exp_le0(d0), x1 = d1 == 0.0 ? 1.0 : exp_le0(d1);
+            const double sum = x0 + x1;                // in [1, 2]
+            e0 = x0 / sum;
+            e1 = x1 / sum;
+            const double z = fcd_log_normal(sum, ltab) + mx;
+            s0 -= z;
+            s1 -= z;
+        } else {
+            const double z = log(exp(d0) + exp(d1)) + mx;       // (not finite somewhere: the reference's own operations)
+            s0 -= z;
+            s1 -= z;
+            e0 = exp(s0);
+            e1 = exp(s1);
+        }
+        if (tid < 2) lq_R[((int64_t)n * U + u) * 2 + tid] = tid == 0 ? s0 : s1;
+#pragma unroll
+        for (int j = 0; j < MPT; ++j) {
+            if (tid + j * BLOCK == n) {
+                q0m[j] = e0;
+                q1m[j] = e1;
+            }
+        }
+    };
+    for (int n = 0; n < Nreg; n += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (n + b < Nreg) step(n + b, buf[b], buf[(b + NB - 1) % NB]);
+    }
+}
+
+// Rounds 1-3's form, kept for shapes whose W would not stay near the chip (cfg5: 0.96 GB): one block per patient, regions
+// strictly in order, the threads split the sum over m and GATHER their operands from the edge-major table inside the loop.  The operands of region n+1 (its 9 table values and 3 q_F per thread and m) do not
 // depend on what region n decides: they are requested before region n is reduced, so the scattered 72-byte table
 // reads (one memory round trip, ~2 us) hide behind the reduction instead of adding up 200 times.
 template <int MPT>   // regions m per thread: Nreg <= MPT * QR_BLOCK
-__global__ __launch_bounds__(QR_BLOCK) void vb_qR_kernel(const double *__restrict__ qF, const double *__restrict__ lM,
+__global__ __launch_bounds__(QR_BLOCK) void vb_qR_gather_kernel(const double *__restrict__ qF, const double *__restrict__ lM,
                                                          const double *__restrict__ hyper, int Nreg, int U, int mode,
                                                          double *__restrict__ lq_R) {
     __shared__ double red[2][2 * (QR_BLOCK / 64)];      // wave partials, double-buffered: one barrier per region
@@ -316,19 +519,40 @@ extern "C" int fcd_vb_update_qR(fcd_ctx *ctx, const double *lq_F, const double *
     if (Nreg > 4 * QR_BLOCK)
         return fcd_fail(ctx, FCD_ERR_UNSUPPORTED, "fcd_vb_update_qR: Nreg=%lld exceeds 4 regions per thread", Nreg);
     const int64_t nF = fcd_tri(Nreg) * 3;
-    rc = fcd_ws_reserve(ctx, (size_t)nF * sizeof(double));
+    const int64_t nW = U * Nreg * Nreg * 3;
+    // the region-major weights pay where they stay near the chip (cfg3: 48 MB; measured 0.315 -> 0.207 ms per update); at
+    // cfg5 they are 0.96 GB and making them costs more than the gathers of the old form save (1.58 against 1.0 ms)
+    const bool weights = Nreg <= 65535 && ctx->knobs.qr_form != 1 && ((size_t)nW * sizeof(double) <= ((size_t)192 << 20) || ctx->knobs.qr_form == 2);
+    rc = fcd_ws_reserve(ctx, (size_t)(nF + (weights ? nW : 0)) * sizeof(double));
     if (rc) return rc;
     double *qF = (double *)ctx->ws;
+    double *W = qF + nF;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vb_expF_kernel, dim3((unsigned)((nF + 255) / 256 < 1024 ? (nF + 255) / 256 : 1024)), dim3(256), 0, s, lq_F, nF, qF);
     FCD_LAUNCH_CHECK();
-    const int mpt = (int)((Nreg + QR_BLOCK - 1) / QR_BLOCK);
-    if (mpt <= 1)
-        hipLaunchKernelGGL(vb_qR_kernel<1>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
-    else if (mpt == 2)
-        hipLaunchKernelGGL(vb_qR_kernel<2>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
-    else
-        hipLaunchKernelGGL(vb_qR_kernel<4>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+    if (!weights) {
+        const int mpt = (int)((Nreg + QR_BLOCK - 1) / QR_BLOCK);
+        if (mpt <= 1)
+            hipLaunchKernelGGL(vb_qR_gather_kernel<1>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+        else if (mpt == 2)
+            hipLaunchKernelGGL(vb_qR_gather_kernel<2>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+        else
+            hipLaunchKernelGGL(vb_qR_gather_kernel<4>, dim3((unsigned)U), dim3(QR_BLOCK), shmem, s, qF, lM, hyper, (int)Nreg, (int)U, edge_mode, lq_R);
+        FCD_LAUNCH_CHECK();
+        return FCD_OK;
+    }
+    hipLaunchKernelGGL(vb_qR_weights_kernel, dim3((unsigned)((Nreg + QW_M - 1) / QW_M), (unsigned)Nreg, (unsigned)((U + 63) / 64)), dim3(64), 0, s,
+                       qF, lM, (int)Nreg, (int)U, edge_mode, W);
+    FCD_LAUNCH_CHECK();
+    const QrTabs *tabs = reinterpret_cast<const QrTabs *>(ctx->log_tab);
+    if (!tabs) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_vb_update_qR: the context holds no exp / log tables");
+#define QR_LAUNCH(WV, MPT, NB) hipLaunchKernelGGL((vb_qR_kernel<WV, MPT, NB>), dim3((unsigned)U), dim3(64 * WV), shmem, s, W, hyper, tabs, (int)Nreg, (int)U, lq_R)
+    if (Nreg <= 64) QR_LAUNCH(1, 1, 6);
+    else if (Nreg <= 128) QR_LAUNCH(1, 2, 6);
+    else if (Nreg <= 256) QR_LAUNCH(1, 4, 4);
+    else if (Nreg <= 512) QR_LAUNCH(1, 8, 3);
+    else QR_LAUNCH(4, 4, 6);
+#undef QR_LAUNCH
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }

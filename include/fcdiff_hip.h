@@ -90,6 +90,9 @@ int fcd_ctx_reserve(fcd_ctx *ctx, int64_t Nreg, int64_t U, int64_t G);
  *               not the default; the default relies on the occupancy query, 8 spare slots and bounded polls)
  *   "r_refill"  1: the pipelined r pass's packing launch writes the panel-value sentinels in every sweep (default: only in the
  *               first sweep of a fcd_gibbs_run call -- a completed pass leaves every slot holding its sentinel again)
+ *   "qr_form"   fcd_vb_update_qR: 1 = operands gathered from the edge-major table inside the region loop (rounds 1-3; the
+ *               default where the region-major weights would exceed 192 MB: cfg5), 2 = region-major weights made first
+ *               whatever their size (the default below that: cfg3)
  *   "corr_form" 1: fcd_corr_edges in 64 x 64 blocks with a moments pass also where the one-workgroup-per-subject kernel
  *               (up to 208 regions) would run
  *   "r_tol", "f_tol"  widen the margin inside which a fast r / f draw is repeated with the exact formula (1e30: all)

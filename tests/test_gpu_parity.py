@@ -206,6 +206,34 @@ def test_update_lq_R_reference_and_symmetric(env):
             nptest.assert_allclose(fit._lq_R, exp, **SUM)
 
 
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("N,U", [(5, 3), (64, 16), (70, 65), (130, 7), (200, 50), (300, 9), (520, 3)])
+def test_update_lq_R_forms_against_oracle(env, knobs, form, N, U):
+    """
+    fcd_vb_update_qR has two forms (knob qr_form): 1 = operands gathered from the edge-major table inside the region loop,
+    2 = region-major weights made first, then one wave per patient (round 4; the default up to 192 MB of weights).  Both
+    against the C oracle's update_lq_R (fcdiff/fit.py:176-198) on the same inputs, every wave count / regions-per-lane
+    variant of the kernels (Nreg <= 64, 128, 256, 512, above), both edge-id modes.
+    """
+    rng = np.random.default_rng(N * 1000 + U)
+    C = N * (N - 1) // 2
+    lM = rng.normal(size=(C, U, 3, 3)) * 2.0
+    q_R = rng.dirichlet([1.0, 1.0], size=(N, U))
+    q_F = rng.dirichlet([1.0, 1.0, 1.0], size=(C, 1))
+    pi2 = np.array([0.7, 0.3])
+    knobs(qr_form=form)
+    for mode in ("reference", "symmetric"):
+        fit = new_fit(env)
+        fit.edge_index = mode
+        fit._lq_R, fit._lq_F, fit._lM = np.log(q_R), np.log(q_F), lM
+        fit.model = env.pkg.UnsharedRegionModel()
+        fit.model.pi = pi2
+        fit._update_lq_R()
+        exp = env.CO.update_lq_R(np.log(q_R), np.log(q_F), lM, pi2, 0 if mode == "reference" else 1)
+        nptest.assert_allclose(fit._lq_R, exp, rtol=1e-9, atol=1e-10)
+        nptest.assert_allclose(np.exp(fit._lq_R).sum(axis=2), 1.0, rtol=1e-12)
+
+
 def test_update_lq_R_reference_ids_need_three_regions(env):
     fit = new_fit(env)
     fit._lq_R = np.log(np.full((2, 3, 2), 0.5))
