@@ -374,8 +374,17 @@ class UnsharedRegionFit(object):
 
     def _update_theta(self):
         """fit.py:200-206."""
-        self._update_pi()
-        self._update_gamma()
+        lq_R, lq_F = self._d.get("lq_R"), self._d.get("lq_F")
+        if (lq_R is not None and lq_F is not None and lq_R.dim() == 3 and lq_F.dim() == 3
+                and int(lq_F.shape[0]) == util.N_to_C(int(lq_R.shape[0]))):
+            # both closed forms come out of ONE launch (and one read-back): the same four numbers _update_pi() and
+            # _update_gamma() would each ask the kernel for
+            out = self._theta_step(lq_R=lq_R, lq_F=lq_F)
+            self.model.pi = float(out[0])
+            self.model.gamma = out[1:4].copy()
+        else:
+            self._update_pi()
+            self._update_gamma()
         if self.update_theta_sub:
             self._update_theta_sub()
 
