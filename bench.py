@@ -286,6 +286,14 @@ def main():
     if r_name in kern:
         lds[r_name] = r_lds_pass / n_step / (kern[r_name]["avg_launch_ms"] * 1e-3) / 1e12
     lds["frac"] = {k: lds[k] / lds_peak for k in (f_name, r_name) if k in lds}
+    # ... and against what the LDS was MEASURED to give this access pattern (round 4): a wave-wide 8-byte GATHER -- every lane
+    # its own address inside a record -- leaves a CU at one instruction per 1.75 ns whatever the number of waves that ask
+    # (profiles/r02_ubench_lds_fp64.txt: 7.0-7.5 ns per read and SIMD slot at 4, 8 and 16 waves per CU), i.e. 64 x 8 B per
+    # ~4 clocks, half the streaming figure above.  The term loops of both kernels are such gathers.
+    gather_ns_per_cu = 1.75
+    lds["gather_peak"] = n_cu * 64 * 8 / gather_ns_per_cu / 1e3                   # TB/s
+    lds["gather_peak_source"] = "profiles/r02_ubench_lds_fp64.txt (b64 gather, panel pattern: 7.01 ns per SIMD slot at 16 waves per CU)"
+    lds["frac_of_gather_peak"] = {k: lds[k] / lds["gather_peak"] for k in (f_name, r_name) if k in lds}
 
     # The bound that binds these two kernels is vector-instruction ISSUE, not bytes: SQ_INSTS_VALU per launch
     # from the committed counter pass of this same command (profiles/pmc_lds_summary.py -> JSON), priced at 2 cycles of a SIMD

@@ -375,9 +375,9 @@ __device__ inline double xlogy0(double q, double lq) { return q == 0.0 ? 0.0 : q
 
 __global__ __launch_bounds__(EN_BLOCK) void vb_energy_edges(const double *__restrict__ lq_F, const double *__restrict__ lq_R,
                                                             const double *__restrict__ S_B, const double *__restrict__ lM,
-                                                            const double *__restrict__ hyper, int64_t C, int U,
+                                                            const double *__restrict__ hyper, int64_t C, int U, int64_t NU,
                                                             double *__restrict__ ws) {
-    __shared__ double acc[4][4];
+    __shared__ double acc[4][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double e_F = 0, e_B = 0, e_M = 0, e_qF = 0;
     for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < C; c += (int64_t)gridDim.x * 4) {
@@ -395,19 +395,32 @@ __global__ __launch_bounds__(EN_BLOCK) void vb_energy_edges(const double *__rest
             }
         }
     }
+    // the two terms over (region, patient), fit.py:486 and :539: a slice per block (round 4; until then ONE block of the
+    // fold kernel walked all Nreg x U of them: 154 us at cfg5)
+    double e_R = 0, e_qR = 0;
+    {
+        const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
+        for (int64_t i = (int64_t)blockIdx.x * EN_BLOCK + threadIdx.x; i < NU; i += (int64_t)gridDim.x * EN_BLOCK) {
+            const double l0 = lq_R[i * 2 + 0], l1 = lq_R[i * 2 + 1];
+            const double q0 = exp(l0), q1 = exp(l1);
+            e_R += q0 * lnpi0 + q1 * lnpi1;                // fit.py:486
+            e_qR += xlogy0(q0, l0) + xlogy0(q1, l1);       // fit.py:539
+        }
+        e_R = fcd_wave_sum(e_R);
+        e_qR = fcd_wave_sum(e_qR);
+    }
     if (lane == 0) {
         acc[wave][0] = e_F; acc[wave][1] = e_B; acc[wave][2] = e_M; acc[wave][3] = e_qF;
+        acc[wave][4] = e_R; acc[wave][5] = e_qR;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 6) {
         const int j = threadIdx.x;
         ws[(int64_t)blockIdx.x * 8 + j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
     }
 }
 
-__global__ __launch_bounds__(256) void vb_energy_fold(const double *__restrict__ ws, int n_blocks,
-                                                      const double *__restrict__ lq_R, const double *__restrict__ hyper,
-                                                      int64_t NU, double *__restrict__ terms6) {
+__global__ __launch_bounds__(256) void vb_energy_fold(const double *__restrict__ ws, int n_blocks, double *__restrict__ terms6) {
     __shared__ double red[4][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v[6] = {0, 0, 0, 0, 0, 0};
@@ -416,13 +429,8 @@ __global__ __launch_bounds__(256) void vb_energy_fold(const double *__restrict__
         v[1] += ws[(int64_t)bI * 8 + 1];
         v[3] += ws[(int64_t)bI * 8 + 2];
         v[4] += ws[(int64_t)bI * 8 + 3];
-    }
-    const double lnpi0 = hyper[FCD_H_LNPI0], lnpi1 = hyper[FCD_H_LNPI1];
-    for (int64_t i = tid; i < NU; i += 256) {
-        const double l0 = lq_R[i * 2 + 0], l1 = lq_R[i * 2 + 1];
-        const double q0 = exp(l0), q1 = exp(l1);
-        v[2] += q0 * lnpi0 + q1 * lnpi1;               // fit.py:486
-        v[5] += xlogy0(q0, l0) + xlogy0(q1, l1);       // fit.py:539
+        v[2] += ws[(int64_t)bI * 8 + 4];
+        v[5] += ws[(int64_t)bI * 8 + 5];
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -433,18 +441,38 @@ __global__ __launch_bounds__(256) void vb_energy_fold(const double *__restrict__
     if (tid < 6) terms6[tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-// ---- theta step: pi* = mean q_R[:,:,1], gamma* = mean_c q_F (fit.py:208-220), one block ----------
-__global__ __launch_bounds__(1024) void vb_theta_kernel(const double *__restrict__ lq_F, const double *__restrict__ lq_R,
+// ---- theta step: pi* = mean q_R[:,:,1], gamma* = mean_c q_F (fit.py:208-220) ----------
+// partial sums of the exponentials in TH_PARTS blocks (fixed slices, fixed order: the same bits every time), then one block
+// folds them (round 4; one block of 1024 threads walked everything before: 18 us at cfg3, 75 us at cfg5)
+constexpr int TH_PARTS = 64;
+__global__ __launch_bounds__(256) void vb_theta_part_kernel(const double *__restrict__ lq_F, const double *__restrict__ lq_R, int64_t C,
+                                                            int64_t NU, double *__restrict__ ws) {
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double v[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < NU; i += (int64_t)gridDim.x * 256) v[0] += exp(lq_R[i * 2 + 1]);
+    for (int64_t c = (int64_t)blockIdx.x * 256 + tid; c < C; c += (int64_t)gridDim.x * 256) {
+        v[1] += exp(lq_F[c * 3 + 0]);
+        v[2] += exp(lq_F[c * 3 + 1]);
+        v[3] += exp(lq_F[c * 3 + 2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double s = fcd_wave_sum(v[j]);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (tid < 4) ws[(int64_t)blockIdx.x * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+__global__ __launch_bounds__(1024) void vb_theta_kernel(const double *__restrict__ ws, int n_parts,
                                                         int64_t C, int64_t NU, double *__restrict__ out4,
                                                         double *__restrict__ hyper) {
     __shared__ double red[16][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v[4] = {0, 0, 0, 0};
-    for (int64_t i = tid; i < NU; i += 1024) v[0] += exp(lq_R[i * 2 + 1]);
-    for (int64_t c = tid; c < C; c += 1024) {
-        v[1] += exp(lq_F[c * 3 + 0]);
-        v[2] += exp(lq_F[c * 3 + 1]);
-        v[3] += exp(lq_F[c * 3 + 2]);
+    for (int i = tid; i < n_parts; i += 1024) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += ws[(int64_t)i * 4 + j];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -571,10 +599,9 @@ extern "C" int fcd_vb_energy(fcd_ctx *ctx, const double *lq_F, const double *lq_
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vb_energy_edges, dim3((unsigned)n_blocks), dim3(EN_BLOCK), 0, s, lq_F, lq_R, S_B, lM, hyper, C,
-                       (int)U, (double *)ctx->ws);
+                       (int)U, Nreg * U, (double *)ctx->ws);
     FCD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vb_energy_fold, dim3(1), dim3(256), 0, s, (const double *)ctx->ws, (int)n_blocks, lq_R, hyper,
-                       Nreg * U, terms6);
+    hipLaunchKernelGGL(vb_energy_fold, dim3(1), dim3(256), 0, s, (const double *)ctx->ws, (int)n_blocks, terms6);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
 }
@@ -584,7 +611,12 @@ extern "C" int fcd_vb_theta_step(fcd_ctx *ctx, const double *lq_F, const double 
     if (!ctx || !lq_F || !lq_R || !out4) return fcd_fail(ctx, FCD_ERR_ARG, "fcd_vb_theta_step: null pointer");
     int rc = check_shape(ctx, "fcd_vb_theta_step", Nreg, U);
     if (rc) return rc;
-    hipLaunchKernelGGL(vb_theta_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lq_F, lq_R, fcd_tri(Nreg),
+    rc = fcd_ws_reserve(ctx, (size_t)TH_PARTS * 4 * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(vb_theta_part_kernel, dim3(TH_PARTS), dim3(256), 0, (hipStream_t)stream, lq_F, lq_R, fcd_tri(Nreg), Nreg * U,
+                       (double *)ctx->ws);
+    FCD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vb_theta_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double *)ctx->ws, TH_PARTS, fcd_tri(Nreg),
                        Nreg * U, out4, hyper);
     FCD_LAUNCH_CHECK();
     return FCD_OK;
