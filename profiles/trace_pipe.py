@@ -88,6 +88,26 @@ def main():
         k = tuple(sorted(v))
         kinds[k] = kinds.get(k, 0) + 1
     print("workgroups per CU by role (1 = P, 2 = D):", kinds)
+    # the panel role's step (start of step L+1 minus start of step L) by what shares its CU
+    idx = np.nonzero(m)[0]
+    kind_of = {}
+    for (i, c) in zip(idx, cuid):
+        kind_of[int(i)] = tuple(sorted(by[int(c)]))
+    for want in sorted(set(kind_of.values())):
+        if 1 not in want:
+            continue
+        wg = [i for i in idx if kind_of[int(i)] == want and (int(t[0, i, 6]) & 255) == 1]
+        if not wg:
+            continue
+        durs, terms, builds = [], [], []
+        for L in range(2, 11):
+            a, b2 = t[L][wg], t[L + 1][wg]
+            okk = (a[:, 0] > 0) & (b2[:, 0] > 0)
+            durs.append(np.median((b2[okk, 0] - a[okk, 0]) / 100.0))
+            builds.append(np.median((a[okk, 1] - a[okk, 0]) / 100.0))
+            terms.append(np.median((a[okk, 4] - a[okk, 2]) / 100.0))
+        print("panel workgroups on CUs holding %s (%d): step %.2f us (build %.2f, sums incl. waits %.2f), median over steps 2-10" % (
+            want, len(wg), np.median(durs), np.median(builds), np.median(terms)))
 
 
 if __name__ == "__main__":
