@@ -55,9 +55,10 @@ those files by `profiles/design_table.py`.)
 | `roofline` (r pass, HBM, per launch — the contract's form) | 112.5 MB / {b3['roofline']['avg_launch_ms']*1e3:.1f} µs = {b3['roofline']['achieved']:.0f} GB/s = **{b3['roofline']['frac']:.3f}**; traffic {b3['roofline']['traffic']/1e6:.0f} MB corrected, {b3['roofline']['traffic_raw_counters']/1e6:.0f} MB raw counters | 66.3 MB / {b5['roofline']['avg_launch_ms']*1e3:.1f} µs = **{b5['roofline']['frac']:.3f}**; traffic {b5['roofline']['traffic']/1e6:.0f} MB |
 | `roofline_valu.frac` (issue slots of the SIMDs: `SQ_INSTS_VALU` × (2 + 2·share of the 4-cycle class) ÷ 1024 SIMDs ÷ kernel cycles) | f: {rv3['gibbs_f_pair_kernel']['insts_valu_per_launch']/1e6:.1f} M instructions → **{rv3['gibbs_f_pair_kernel']['frac']:.2f}**; r: {rv3['gibbs_r_pipe_kernel']['insts_valu_per_launch']/1e6:.1f} M → **{rv3['gibbs_r_pipe_kernel']['frac']:.2f}** (round 3: f 61.0 M, r 105.8 M) | r step: {rv5['gibbs_r_step_kernel']['insts_valu_per_launch']/1e6:.1f} M → **{rv5['gibbs_r_step_kernel']['frac']:.2f}** |
 | `lds_roofline.frac` (f / r, against 256 B/clk and CU) | {b3['lds_roofline']['frac']['gibbs_f_pair_kernel']:.2f} / {b3['lds_roofline']['frac']['gibbs_r_pipe_kernel']:.2f} (f: 8-byte reads now) | {b5['lds_roofline']['frac']['gibbs_f_pair_kernel']:.2f} / {b5['lds_roofline']['frac']['gibbs_r_step_kernel']:.2f} |
+| `lds_roofline.frac_of_gather_peak` (f / r: the same bytes against what the LDS was MEASURED to give wave-wide 8-byte gathers, one per 1.75 ns and CU, `r02_ubench_lds_fp64.txt`) | **{b3['lds_roofline']['frac_of_gather_peak']['gibbs_f_pair_kernel']:.2f} / {b3['lds_roofline']['frac_of_gather_peak']['gibbs_r_pipe_kernel']:.2f}** — whole-kernel averages; inside the term loops the LDS is saturated (32 waves × 4 gathers in flight per CU, ≈550 clocks per batch of four: `r04_grouped_scan_experiment.txt`, `r04_half_block_handover_experiment.txt`) | {b5['lds_roofline']['frac_of_gather_peak']['gibbs_f_pair_kernel']:.2f} / {b5['lds_roofline']['frac_of_gather_peak']['gibbs_r_step_kernel']:.2f} |
 | K_lik | {trace_us(3,'lik_kernel'):.1f} µs in the trace, {b3['lik_tables']['avg_launch_ms']*1e3:.1f} µs between events = **{b3['lik_tables']['frac']:.2f}** of 8 TB/s | {b5['lik_tables']['avg_launch_ms']:.3f} ms = **{b5['lik_tables']['frac']:.2f}** |
 | K_corr | **{b3['corr']['ms']:.4f} ms = {b3['corr']['achieved']:.1f} TFLOP/s = {b3['corr']['frac']:.3f}** of the 78.6 TFLOP/s datasheet peak (kernel {trace_us(3,'corr_gram_subject_kernel'):.1f} + transpose {trace_us(3,'corr_transpose_kernel'):.1f} µs in the trace) | {b5['corr']['ms']:.2f} ms = {b5['corr']['frac']:.3f} (block kernel: Nreg = 400 > 208) |
-| the reference's own algorithm: one variational iteration (`vb_iteration`) | **{b3['vb_iteration']['gpu_ms']:.3f} ms** on the GPU (`r04_vb_iter.txt`: q_F {parts.group(1)}, q_R {parts.group(2)}, θ {parts.group(3)}, tables {parts.group(4)}, energy {parts.group(5)}) against {b3['vb_iteration']['cpu_faithful_s']:.2f} s in the reference's structure (Python loop over edges, one core), {b3['vb_iteration']['cpu_vectorised_s']:.2f} s as whole-array NumPy, {b3['vb_iteration']['cpu_c_openmp_s']:.2f} s C/OpenMP on 128 cores; all four land on the same energy (−3 571 729.6747); round 3: 8.6 ms | **{b5['vb_iteration']['gpu_ms']:.2f} ms** against {b5['vb_iteration']['cpu_c_openmp_s']:.2f} s (C/OpenMP); round 3: 165 ms |
+| the reference's own algorithm: one variational iteration (`vb_iteration`) | **{b3['vb_iteration']['gpu_ms']:.3f} ms** on the GPU (`r04_vb_iter.txt`: q_F {parts.group(1)}, q_R {parts.group(2)}, θ {parts.group(3)}, tables {parts.group(4)}, energy {parts.group(5)}) against {b3['vb_iteration']['cpu_faithful_s']:.2f} s in the reference's structure (Python loop over edges, one core), {b3['vb_iteration']['cpu_vectorised_s']:.2f} s as whole-array NumPy, {b3['vb_iteration']['cpu_c_openmp_s']:.2f} s C/OpenMP on 128 cores; all four land on the same energy (−3 571 729.6747); round 3: 8.6 ms, first session of round 4: 0.566 ms | **{b5['vb_iteration']['gpu_ms']:.2f} ms** against {b5['vb_iteration']['cpu_c_openmp_s']:.2f} s (C/OpenMP); round 3: 165 ms, first session of round 4: 2.51 ms |
 | several-rank loop on an RCCL process group of ONE rank (`--force-pg`, 500 steps) | library's communicator on the compute stream: **{pg['ms_per_step']:.4f} ms** ({(pg['ms_per_step']/b500['ms_per_step']-1)*100:+.1f} % against {b500['ms_per_step']:.4f}; other sessions of the round: +0.5 %, +0.8 %, +1.0 %; `fcd_allreduce_stats` alone {pg['config']['allreduce_us']:.1f} µs per call — on ONE rank RCCL launches no kernel for the in-place all-reduce (`r04_rccl_kernel_footprint.txt` is empty): what is measured is the call and the separate M-step launch); through torch.distributed (round 3's loop, lagged): {pgt['ms_per_step']:.4f} ms ({(pgt['ms_per_step']/b500['ms_per_step']-1)*100:+.1f} %, all-reduce {pgt['config']['allreduce_us']:.1f} µs) | — |
 | C restatement on 128 host cores (mode iii) | {b3['cpu_baseline']['value']:.0f} samples/s | {b5['cpu_baseline']['value']:.1f} samples/s |
 
