@@ -809,7 +809,6 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
     const int w = __builtin_amdgcn_readfirstlane((int)(wg * a.wpb + (threadIdx.x >> 6)));
     const bool live = w < a.GW;
     const int wl = live ? w : 0;
-    const double dpi = a.hyper[FCD_H_LNPI1] - a.hyper[FCD_H_LNPI0];
     const int row_d2 = Nreg * 3, pad_d2 = NBLK * R_NB * 3, total = UB * pad_d2;
     constexpr int SU = 2;                                  // 16-byte pieces of the rows per thread and turn
     bool ok = true;
@@ -887,6 +886,19 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
         unsigned txp = threadIdx.x;                           // (opaque copy: the piece index is made here, not carried -- spilled -- across the step)
         asm volatile("" : "+v"(txp));
         if (more) load_rows(n + R_NB, (int)txp, nv);
+        // The marks of block st-2 (one per patient) are ASKED FOR here, a whole threshold computation and most of the sums
+        // before they are needed: in the usual case they have long been set, and the two memory-side trips of the poll (one
+        // per patient, one after the other: ~1.4 us at the end of every step) are off the step.  A mark only ever goes
+        // 0 -> 1 inside a pass, so an early 1 is final; an early 0 falls back to the poll where the bytes are needed.
+        uint32_t mk[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            mk[u] = 1u;
+            if (st >= 2) {
+                const int uu = u < nu ? u : nu - 1;
+                mk[u] = __hip_atomic_load(a.flags + ((int64_t)wl * U + u0 + uu) * NBLK + (st - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         double th[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) th[u] = 0.0;
@@ -911,6 +923,9 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
             }
         }
         staged = more;
+        bool seen[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) seen[u] = __builtin_amdgcn_readfirstlane((int)mk[u]) != 0;
         if (!live) continue;
         FCD_TRACE(trec, 2);
         // The sums run over the blocks ABOVE the current one first (their r bytes are the old ones, made before the pass),
@@ -934,7 +949,7 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
             if (!polled && jlast >= NV - 1) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (u < nu) pipe_poll_mark(a.flags + ((int64_t)wl * U + u0 + u) * NBLK + (st - 2), a.poll_limit, err, ok);
+                    if (u < nu && !seen[u]) pipe_poll_mark(a.flags + ((int64_t)wl * U + u0 + u) * NBLK + (st - 2), a.poll_limit, err, ok);
                 polled = true;
                 FCD_TRACE(trec, 3);
             }
@@ -990,6 +1005,11 @@ __device__ __forceinline__ void pipe_panel(const r_step_args &a, int row, int uc
                 }
             }
         }
+        // (ln pi - ln(1 - pi) read HERE, behind an index the compiler cannot see through: lifted out of the step loop it is one
+        //  more value alive across the sums -- spilled, and fetched back from scratch memory right in front of this store)
+        int hz = 0;
+        asm volatile("" : "+s"(hz));
+        const double dpi = a.hyper[FCD_H_LNPI1 + hz] - a.hyper[FCD_H_LNPI0 + hz];
 #pragma unroll
         for (int u = 0; u < UB; ++u)
             if (u < nu) st_d<true>(a.Pbuf[st & 1] + (((int64_t)w * U + u0 + u) * R_NB + row) * 64 + ulane, (dpi + d[u]) - th[u]);
