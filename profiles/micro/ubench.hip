@@ -13,6 +13,10 @@
 // MODE 3: ds_read_b128, 3 distinct 16-byte addresses (f-step pattern)
 // MODE 4: no LDS: v_add_f64 only
 // MODE 5: ds_read_b64 pattern 0 without the add (read + xor into an int accumulator)
+// MODE 6: ds_read_b32 gather (6 addresses) + v_add_u32 (round 4: is a 4-byte gather cheaper than an 8-byte one?)
+// MODE 7 / 8: ds_read_b128 / ds_read_b64 gather of which ONE dword is used -- the compiler shrinks both to ds_read_b32
+// MODE 9: ds_read_b64 gather + 64-bit INTEGER add (fixed-point sums: v_lshl_add_u64)
+// MODE 10: ds_read_b64 gather + v_pk_add_f32 (two fp32 sums side by side)
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long *cyc, int iters) {
     __shared__ __attribute__((aligned(16))) double lds[8192];
@@ -21,11 +25,16 @@ __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long
     const int lane = threadIdx.x & 63;
     const int s = sel[threadIdx.x & 63];     // 0..5
     uint32_t a;
-    if (MODE == 0 || MODE == 5) a = s * 8;
+    if (MODE == 0 || MODE == 5 || MODE == 8 || MODE == 9 || MODE == 10) a = s * 8;
+    else if (MODE == 6) a = s * 4;
     else if (MODE == 1) a = lane * 8;
     else if (MODE == 2) a = 0;
     else a = (s % 3) * 16;
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v p0 = {0, 0}, p1 = {0, 0}, p2 = {0, 0}, p3 = {0, 0};
     const char *b = (const char *)lds;
     const long long rt0 = (long long)wall_clock64();
     long long t0 = __builtin_amdgcn_s_memtime();
@@ -35,6 +44,24 @@ __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long
             const uint32_t o = (uint32_t)((it & 7) * 6144 + j * 192);
             if (MODE == 4) {
                 d0 += 1.0000001; d1 += 1.0000002; d2 += 1.0000003; d3 += 1.0000004;
+            } else if (MODE == 6) {
+                i0 += *(const uint32_t *)(b + a + o); i1 += *(const uint32_t *)(b + a + o + 48);
+                i2 += *(const uint32_t *)(b + a + o + 96); i3 += *(const uint32_t *)(b + a + o + 144);
+            } else if (MODE == 7) {
+                const uint4 v0 = *(const uint4 *)(b + (a & ~15u) + o), v1 = *(const uint4 *)(b + (a & ~15u) + o + 48);
+                const uint4 v2 = *(const uint4 *)(b + (a & ~15u) + o + 96), v3 = *(const uint4 *)(b + (a & ~15u) + o + 144);
+                i0 ^= v0.x; i1 ^= v1.y; i2 ^= v2.z; i3 ^= v3.w;
+            } else if (MODE == 8) {
+                const uint2 v0 = *(const uint2 *)(b + a + o), v1 = *(const uint2 *)(b + a + o + 48);
+                const uint2 v2 = *(const uint2 *)(b + a + o + 96), v3 = *(const uint2 *)(b + a + o + 144);
+                i0 ^= v0.x; i1 ^= v1.y; i2 ^= v2.x; i3 ^= v3.y;
+            } else if (MODE == 9) {
+                q0 += *(const unsigned long long *)(b + a + o); q1 += *(const unsigned long long *)(b + a + o + 48);
+                q2 += *(const unsigned long long *)(b + a + o + 96); q3 += *(const unsigned long long *)(b + a + o + 144);
+            } else if (MODE == 10) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                p0 += *(const f2 *)(b + a + o); p1 += *(const f2 *)(b + a + o + 48);
+                p2 += *(const f2 *)(b + a + o + 96); p3 += *(const f2 *)(b + a + o + 144);
             } else if (MODE == 3) {
                 const double2 v0 = *(const double2 *)(b + a + o), v1 = *(const double2 *)(b + a + o + 48);
                 d0 += v0.x; d1 += v0.y; d2 += v1.x; d3 += v1.y;
@@ -47,7 +74,7 @@ __global__ __launch_bounds__(1024) void k(const int *sel, double *out, long long
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = d0 + d1 + d2 + d3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = d0 + d1 + d2 + d3 + (double)(i0 + i1 + i2 + i3) + (double)(q0 + q1 + q2 + q3) + (double)(p0.x + p1.y + p2.x + p3.y);
     if (threadIdx.x == 0) {
         cyc[blockIdx.x] = t1 - t0;
         cyc[256 + blockIdx.x] = rt0;                       // 100 MHz wall clock at the start / end of the loop
@@ -105,6 +132,11 @@ int main() {
         run<2>("b64 all lanes same address", wpb, sel, out, cyc);
         run<3>("b128 3 addrs (f pattern; 2 reads+4 adds/grp)", wpb, sel, out, cyc);
         run<4>("v_add_f64 only (4 adds/grp)", wpb, sel, out, cyc);
+        run<6>("b32 gather 6 addrs + v_add_u32", wpb, sel, out, cyc);
+        run<8>("b64 gather 6 addrs, one dword used (= b32)", wpb, sel, out, cyc);
+        run<7>("b128 gather 3 addrs, one dword used (= b32)", wpb, sel, out, cyc);
+        run<9>("b64 gather 6 addrs + 64-bit integer add", wpb, sel, out, cyc);
+        run<10>("b64 gather 6 addrs + v_pk_add_f32", wpb, sel, out, cyc);
     }
     return 0;
 }
