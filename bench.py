@@ -287,9 +287,10 @@ def main():
         lds[r_name] = r_lds_pass / n_step / (kern[r_name]["avg_launch_ms"] * 1e-3) / 1e12
     lds["frac"] = {k: lds[k] / lds_peak for k in (f_name, r_name) if k in lds}
     # ... and against what the LDS was MEASURED to give this access pattern (round 4): a wave-wide 8-byte GATHER -- every lane
-    # its own address inside a record -- leaves a CU at one instruction per 1.75 ns whatever the number of waves that ask
-    # (profiles/r02_ubench_lds_fp64.txt: 7.0-7.5 ns per read and SIMD slot at 4, 8 and 16 waves per CU), i.e. 64 x 8 B per
-    # ~4 clocks, half the streaming figure above.  The term loops of both kernels are such gathers.
+    # its own address inside a record -- leaves a CU at one read per 1.75 ns whatever the number of waves that ask and whatever
+    # adds the values up (profiles/r02_ubench_lds_fp64.txt, r04_ubench_lds_gather.txt: 6.8-7.5 ns per read and SIMD slot at 4, 8
+    # and 16 waves per CU; a gather costs its bytes, 128 B per clock and CU), half the streaming figure above.  The term loops
+    # of both kernels are such gathers.
     gather_ns_per_cu = 1.75
     lds["gather_peak"] = n_cu * 64 * 8 / gather_ns_per_cu / 1e3                   # TB/s
     lds["gather_peak_source"] = "profiles/r02_ubench_lds_fp64.txt (b64 gather, panel pattern: 7.01 ns per SIMD slot at 16 waves per CU)"
